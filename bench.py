@@ -1,0 +1,322 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X ranking-loss hot path.
+
+    python bench.py --gpus N --steps K --warmup W            (N=1: run directly)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): queries/sec of loss forward+backward on the MSLR-WEB30K-shaped padded
+batch B=1024, list_len=128, 136 features (configs[1]), plus achieved HBM GB/s of the dominant
+kernel against the gfx950 roofline.  One "step" is the reference's training-step slice on one
+batch (examples/01-basic-usage.py:70-75):
+
+    loss = loss_fn(Linear(136, 1)(xs), ys, n).mean();  loss.backward()
+
+computed by the fused HIP path (scores -> PairwiseHingeLoss -> d/dW, d/db), inputs resident in
+HBM.  N > 1: one process per GPU, every rank owns its own B queries (weak scaling; queries are
+independent, no data-path collective) and the scorer gradients + (loss sum, count) are
+all-reduced in one RCCL bucket per step.
+
+Prints ONE JSON line on rank 0.  The same line carries
+  roofline      the dominant kernel (fused scorer+loss) timed live with HIP events,
+                algorithmic bytes / launch duration against 8 TB/s HBM3E;
+  cpu_baseline  the materialising CPU port of the reference path (oracle/materialized_torch.py)
+                timed on this box's host cores (rank 0, N=1 only);
+  extra         loss-only drop-in numbers, eager vs hipGraph, per-kernel times.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 achievable
+
+WORKLOADS = {
+    # name: (B, L, F, loss kind)   -- BASELINE.json configs
+    "c2": (1024, 128, 136, "hinge"),
+    "c3": (1024, 128, 136, "ndcg2"),
+    "c4": (256, 1000, 220, "dcg_hinge"),
+    "c5": (512, 512, 700, "hinge"),
+}
+
+
+def synth(B, L, F, seed, device):
+    """SURVEY.md section 8(d) recipe (CPU generator, then .to(device))."""
+    g = torch.Generator().manual_seed(seed)
+    scores = torch.randn(B, L, generator=g)
+    relevance = torch.randint(0, 5, (B, L), generator=g)
+    n = torch.randint(1, L + 1, (B,), generator=g)
+    X = torch.randn(B, L, F, generator=g)
+    return scores.to(device), relevance.to(device), n.to(device), X.to(device)
+
+
+def time_events(fn, iters):
+    """Average per-launch duration (us) of fn() with one HIP event pair per launch, recorded
+    on the stream the kernels are launched on (torch's current stream)."""
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+    torch.cuda.synchronize()
+    for i in range(iters):
+        starts[i].record()
+        fn()
+        ends[i].record()
+    torch.cuda.synchronize()
+    per = sorted(s.elapsed_time(e) * 1e3 for s, e in zip(starts, ends))
+    return sum(per) / len(per), per[len(per) // 2], per[0]
+
+
+def time_wall(fn, steps, barrier):
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def try_graph(step, warm=3):
+    """Capture `step` (forward + backward) into a hipGraph; returns replay fn or None."""
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warm):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        return graph.replay
+    except Exception as exc:  # pragma: no cover - depends on the runtime
+        sys.stderr.write("[bench] hipGraph capture unavailable: %r\n" % (exc,))
+        torch.cuda.synchronize()
+        return None
+
+
+def cpu_baseline(kind, B, L, F, reps=5):
+    """The reference-equivalent CPU path (materialising torch port) on this box's cores."""
+    from oracle import materialized_torch as M
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    _, relevance, n, X = synth(B, L, F, 0, "cpu")
+    lin = torch.nn.Linear(F, 1)
+    M.linear_step(kind, X, lin.weight, lin.bias, relevance, n)          # warm-up
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        M.linear_step(kind, X, lin.weight, lin.bias, relevance, n)
+        ts.append(time.perf_counter() - t0)
+    med = sorted(ts)[len(ts) // 2]
+    scores = torch.randn(B, L)
+    M.loss_step(kind, scores, relevance, n)
+    t0 = time.perf_counter()
+    M.loss_step(kind, scores, relevance, n)
+    loss_only = time.perf_counter() - t0
+    # the scalar C oracle, one core, for information
+    from oracle import ltr_oracle as O
+    t0 = time.perf_counter()
+    O.pairwise_loss(kind, scores.numpy(), relevance.numpy(), n.numpy())
+    c_scalar = time.perf_counter() - t0
+    return {
+        "value": B / med, "unit": "queries/s", "cores": cores, "kind": "port",
+        "sample": "median of %d full steps (Linear(%d,1)+%s fwd+bwd, B=%d, L=%d) of "
+                  "oracle/materialized_torch.py, %d torch threads" % (reps, F, kind, B, L, cores),
+        "ms_per_step": med * 1e3,
+        "loss_only_queries_per_s": B / loss_only,
+        "c_oracle_scalar_1core_queries_per_s": B / c_scalar,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-graph", action="store_true", help="time the eager autograd path only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-lists", action="store_true", help="n == list_len for every query")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    n_gpus = world
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    from pytorchltr_amd import _C
+    from pytorchltr_amd import loss as L_
+    from pytorchltr_amd.distributed import allreduce_step
+    from pytorchltr_amd.fused import FusedLinearLoss
+    _C.lib()                                            # fail loudly if the extension is missing
+
+    B, L, F, kind = WORKLOADS[args.workload]
+    scores, relevance, n, X = synth(B, L, F, 1000 * rank, dev)
+    if args.full_lists:
+        n = torch.full_like(n, L)
+    fused = FusedLinearLoss(F, kind).to(dev)
+    params = [fused.weight, fused.bias]
+
+    # ---- the step: fused scorer + loss forward, backward to dW/db (sum; the all-reduce
+    # bucket turns it into the global mean), all-reduce when sharded over ranks ----
+    def fwd_bwd():
+        for p in params:
+            p.grad = None
+        per_query = fused(X, relevance, n)
+        total = per_query.sum()
+        total.backward()
+        return total
+
+    state = {}
+
+    def step_eager():
+        state["loss_sum"] = fwd_bwd().detach()
+        if dist is not None:
+            state["mean_loss"], _ = allreduce_step([p.grad for p in params], state["loss_sum"], B)
+
+    replay = None if args.no_graph else try_graph(lambda: state.__setitem__("loss_sum", fwd_bwd().detach()))
+
+    def step_graph():
+        replay()
+        if dist is not None:
+            state["mean_loss"], _ = allreduce_step([p.grad for p in params], state["loss_sum"], B)
+
+    results = {}
+    for name, fn in (("eager", step_eager), ("hipgraph", step_graph if replay else None)):
+        if fn is None:
+            continue
+        for _ in range(args.warmup):
+            fn()
+        elapsed = time_wall(fn, args.steps, barrier)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        results[name] = float(t.item())
+    mode = "hipgraph" if "hipgraph" in results else "eager"
+    elapsed = results[mode]
+    value = n_gpus * B * args.steps / elapsed
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: fused scorer+loss, timed live with HIP events ----
+        lib = _C.lib()
+        W = fused.weight.detach().reshape(F).contiguous()
+        bvec = fused.bias.detach().reshape(1).contiguous()
+        lossv = torch.empty(B, device=dev)
+        part = torch.empty(B, F + 1, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def launch_fused():
+            _C.check(lib.ltr_linear_partials_f32(
+                getattr(_C, kind.upper()), 1.0, X.data_ptr(), W.data_ptr(), bvec.data_ptr(),
+                relevance.data_ptr(), _C.LABEL_I64, n.data_ptr(), B, L, F, lossv.data_ptr(), None,
+                part.data_ptr(), stream))
+
+        for _ in range(10):
+            launch_fused()
+        k_avg, k_med, k_min = time_events(launch_fused, 100)
+        # algorithmic bytes per query of the fused step: features 4LF read
+        # once + labels 8L + n 8 + W/bias 4(F+1) amortised per launch + loss 4 + partials 4(F+1)
+        alg_bytes = B * (4 * L * F + 8 * L + 8 + 4 + 4 * (F + 1)) + 4 * (F + 1)
+        achieved = alg_bytes / (k_avg * 1e-6) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic = json.load(fh).get("hbm_bytes_per_launch")
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "kernel": "linear_pairwise_kernel<%s>" % kind,
+                    "kernel_us_avg": k_avg, "kernel_us_median": k_med, "kernel_us_min": k_min,
+                    "algorithmic_bytes_per_launch": alg_bytes}
+
+        # ---- loss-only drop-in path (the literal "loss fwd+bwd" of the metric) ----
+        loss_cls = {"hinge": L_.PairwiseHingeLoss, "dcg_hinge": L_.PairwiseDCGHingeLoss,
+                    "logistic": L_.PairwiseLogisticLoss, "arp1": L_.LambdaARPLoss1,
+                    "arp2": L_.LambdaARPLoss2, "ndcg1": L_.LambdaNDCGLoss1,
+                    "ndcg2": L_.LambdaNDCGLoss2}[kind]
+        loss_fn = loss_cls()
+        sc = scores.clone().requires_grad_(True)
+
+        def loss_step():
+            sc.grad = None
+            loss_fn(sc, relevance, n).mean().backward()
+
+        extra = {"step_seconds": results}
+        for _ in range(args.warmup):
+            loss_step()
+        t_loss = time_wall(loss_step, args.steps, lambda: None)
+        extra["loss_only_eager_queries_per_s"] = B * args.steps / t_loss
+        lreplay = None if args.no_graph else try_graph(loss_step)
+        if lreplay is not None:
+            t_lg = time_wall(lreplay, args.steps, lambda: None)
+            extra["loss_only_hipgraph_queries_per_s"] = B * args.steps / t_lg
+        dsc = torch.empty(B, L, device=dev)
+
+        def launch_loss():
+            _C.check(lib.ltr_pairwise_loss_f32(
+                getattr(_C, kind.upper()), 1.0, scores.data_ptr(), relevance.data_ptr(),
+                _C.LABEL_I64, n.data_ptr(), B, L, lossv.data_ptr(), dsc.data_ptr(), stream))
+
+        for _ in range(10):
+            launch_loss()
+        l_avg, l_med, l_min = time_events(launch_loss, 100)
+        loss_bytes = B * (16 * L + 16)
+        extra["loss_kernel"] = {"kernel": "pairwise_loss_kernel<%s>" % kind, "us_avg": l_avg,
+                                "us_median": l_med, "us_min": l_min,
+                                "algorithmic_bytes_per_launch": loss_bytes,
+                                "achieved_GBs": loss_bytes / (l_avg * 1e-6) / 1e9,
+                                "frac_of_hbm_peak": loss_bytes / (l_avg * 1e-6) / 1e9 / HBM_PEAK_GBS}
+        extra["eager_queries_per_s"] = n_gpus * B * args.steps / results["eager"]
+
+        cpu = None
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(kind, B, L, F)
+
+        out = {
+            "metric": "queries/sec loss fwd+bwd (B=%d, list_len=%d) + achieved HBM GB/s" % (B, L),
+            "value": value, "unit": "queries/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%s: Linear(%d,1) scorer + %s loss fwd+bwd, B=%d/GPU, "
+                                   "list_len=%d, n~U[1,%d]%s" % (args.workload, F, kind, B, L, L,
+                                                                " (full lists)" if args.full_lists else ""),
+                       "global_batch": n_gpus * B, "list_len": L, "features": F, "loss": kind,
+                       "mode": mode, "parallelism": "dp%d" % n_gpus},
+            "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
+        }
+    barrier()
+    if dist is not None:
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

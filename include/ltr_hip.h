@@ -1,0 +1,158 @@
+/*
+ * ltr_hip.h -- C ABI of the MI355X (gfx950) ranking-loss / ranking-metric hot path.
+ *
+ * Drop-in boundary for rjagerman/pytorchltr's per-batch loss + evaluation path.  The
+ * reference has no FFI on this path (it is pure PyTorch); its boundary is the Python
+ * surface listed next to each entry point below (file:line relative to the upstream
+ * tree, v0.2.1).  Each function here computes what that Python symbol computes, on
+ * padded (B, L) row-major device buffers, without ever materialising the (B, L, L[, 2])
+ * pair tensors the reference builds (utils/tensor_operations.py:94-119).
+ *
+ * Conventions (all entry points)
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. the PyTorch caching
+ *     allocator); buffers are contiguous, row-major; nothing is allocated or freed here;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued asynchronously on it,
+ *     no host synchronisation, no globals, re-entrant, callable from any host thread;
+ *   - return value: 0 = OK; < 0 = argument error (LTR_ERR_*); > 0 = a hipError_t from the
+ *     launch.  ltr_error_string() renders either.
+ *   - scores are fp32.  Labels (`rel`) may be int64 (what the reference's collate_fn emits,
+ *     datasets/svmrank/svmrank.py:149-152), int32 or fp32, selected by `rel_dtype`; they
+ *     are narrowed to fp32 in registers (exact for |y| < 2^24).  `n` is int64 (B).
+ *   - n[b] is clamped to [0, L] exactly as the reference's masks act
+ *     (`arange >= n`, utils/tensor_operations.py:25; `n_grid <= range_grid`,
+ *     loss/pairwise_additive.py:75-81).
+ *   - ranking ties: masked score descending, then document index ascending
+ *     (deterministic replacement of the reference's global-RNG tie-break,
+ *     utils/tensor_operations.py:43-45).
+ */
+#ifndef LTR_HIP_H
+#define LTR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LTR_VERSION 100 /* 0.1.0 */
+
+/* Loss kinds: one per class exported by pytorchltr/loss/__init__.py:1-7. */
+enum ltr_loss_kind {
+    LTR_HINGE = 0,     /* PairwiseHingeLoss     loss/pairwise_additive.py:93-113  */
+    LTR_DCG_HINGE = 1, /* PairwiseDCGHingeLoss  loss/pairwise_additive.py:116-133 */
+    LTR_LOGISTIC = 2,  /* PairwiseLogisticLoss  loss/pairwise_additive.py:136-163 */
+    LTR_ARP1 = 3,      /* LambdaARPLoss1        loss/pairwise_lambda.py:95-117    */
+    LTR_ARP2 = 4,      /* LambdaARPLoss2        loss/pairwise_lambda.py:120-140   */
+    LTR_NDCG1 = 5,     /* LambdaNDCGLoss1       loss/pairwise_lambda.py:143-173   */
+    LTR_NDCG2 = 6      /* LambdaNDCGLoss2       loss/pairwise_lambda.py:176-218   */
+};
+
+enum ltr_label_dtype {
+    LTR_LABEL_I64 = 0,
+    LTR_LABEL_F32 = 1,
+    LTR_LABEL_I32 = 2
+};
+
+#define LTR_OK 0
+#define LTR_ERR_NULL (-1)        /* a required pointer is NULL                     */
+#define LTR_ERR_SHAPE (-2)       /* B < 0, L <= 0, F <= 0 or k < 0                 */
+#define LTR_ERR_KIND (-3)        /* unknown loss kind / label dtype                */
+#define LTR_ERR_LIST_TOO_LONG (-4) /* L > ltr_max_list_len()                       */
+#define LTR_ERR_WORKSPACE (-5)   /* workspace NULL or smaller than ltr_*_workspace_bytes */
+#define LTR_ERR_CONFIG (-6)      /* invalid explicit launch configuration          */
+
+int ltr_version(void);
+const char *ltr_error_string(int code);
+/* Largest list_len one workgroup's LDS holds (all kinds). */
+int ltr_max_list_len(void);
+
+/*
+ * Seven pairwise losses, forward + analytic gradient in ONE pass.
+ * Replaces _PairwiseAdditiveLoss.forward (loss/pairwise_additive.py:51-90) and
+ * LambdaLoss.forward (loss/pairwise_lambda.py:50-92) together with the autograd graph
+ * the reference replays for backward.
+ *   loss[b]      = per-query loss (what forward() returns), fp32 (B)
+ *   dscores[b,j] = d loss[b] / d scores[b,j], fp32 (B,L); may be NULL (forward only).
+ *                  Entries j >= n[b] are written as 0.
+ */
+int ltr_pairwise_loss_f32(int kind, float sigma, const float *scores, const void *rel,
+                          int rel_dtype, const int64_t *n, int B, int L, float *loss,
+                          float *dscores, void *stream);
+
+/* Same, with an explicit launch shape (tuning/tests): `owners` threads each own `dpt`
+ * documents per chunk, the pair loop is split `msplit` ways; block = owners*msplit
+ * threads.  owners % 64 == 0, dpt in {1,2,4}, owners*msplit <= 1024. */
+int ltr_pairwise_loss_f32_cfg(int kind, float sigma, const float *scores, const void *rel,
+                              int rel_dtype, const int64_t *n, int B, int L, float *loss,
+                              float *dscores, int owners, int dpt, int msplit, void *stream);
+
+/*
+ * Backward of the reference's per-query output w.r.t. scores: out[b,j] = grad_out[b] *
+ * dscores[b,j] (what autograd computes for `loss.mean().backward()`, with grad_out = 1/B).
+ * `out` may alias `dscores`.
+ */
+int ltr_scale_rows_f32(const float *dscores, const float *grad_out, int B, int L, float *out,
+                       void *stream);
+
+/* rank_by_score, utils/tensor_operations.py:48-64 (mask_padded_values :6-26 +
+ * tiebreak_argsort :29-45).  ranking[b,r] = index of the document at rank r (int64). */
+int ltr_rank_by_score_f32(const float *scores, const int64_t *n, int B, int L,
+                          int64_t *ranking, void *stream);
+
+/*
+ * dcg (evaluation/dcg.py:41-99) and, with normalize != 0, ndcg (evaluation/dcg.py:8-38).
+ *   k > 0 : out is (B), metric@min(k,L);   k == 0 : out is (B,L), the metric at every rank.
+ *   use_exp != 0 : gains 2^y - 1, else y.
+ * As in the reference, labels of padded documents are NOT masked here.
+ */
+int ltr_dcg_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n, int B,
+                int L, int k, int use_exp, int normalize, float *out, void *stream);
+
+/* arp, evaluation/arp.py:7-42.  out is (B). */
+int ltr_arp_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n, int B,
+                int L, float *out, void *stream);
+
+/* mask_padded_values, utils/tensor_operations.py:6-26: out[b,j] = j >= n[b] ? mask_value
+ * : xs[b,j].  `out` may alias `xs` (mutate=True). */
+int ltr_mask_padded_values_f32(const float *xs, const int64_t *n, int B, int L,
+                               float mask_value, float *out, void *stream);
+
+/* batch_pairs, utils/tensor_operations.py:94-119: out[b,i,j,0] = x[b,i], out[b,i,j,1] =
+ * x[b,j]; out is (B,L,L,2).  elem_bytes is 4 (fp32/int32) or 8 (int64/fp64): the copy is
+ * dtype-agnostic.  Only for callers that want the materialised tensor -- the losses above
+ * never build it. */
+int ltr_batch_pairs(const void *x, int elem_bytes, int B, int L, void *out, void *stream);
+
+/*
+ * Linear scorer fused with the loss: the caller of the path in every reference workflow,
+ *   loss_fn(torch.nn.Linear(F,1)(xs), ys, n)  ... .backward()
+ * (examples/01-basic-usage.py:70-75, tests/test_integration.py:42-52).
+ *   X (B,L,F) fp32, W (F), bias (1, device)  ->  scores (B,L) [optional output], loss (B),
+ *   dW (F) and db (1) = d( sum_b grad_out[b]*loss[b] ) / d{W, bias}.
+ * grad_out (B) may be NULL, meaning 1/B for every query (`.mean().backward()`).
+ * Rows l >= n[b] are never read (their gradient is 0) unless scores_out is requested; when
+ * the (L x F) tile fits in LDS the features cross HBM exactly once.
+ * `workspace` needs ltr_linear_workspace_bytes(B,L,F) bytes (per-query partials).
+ */
+size_t ltr_linear_workspace_bytes(int B, int L, int F);
+int ltr_linear_pairwise_f32(int kind, float sigma, const float *X, const float *W,
+                            const float *bias, const void *rel, int rel_dtype,
+                            const int64_t *n, const float *grad_out, int B, int L, int F,
+                            float *loss, float *scores_out, float *dW, float *db,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
+/* The same step split at the autograd boundary (forward / backward of a fused
+ * Linear+loss module): partials[b, 0..F) = d loss[b] / dW, partials[b, F] = d loss[b] / d bias,
+ * then dW = sum_b grad_out[b] * partials[b, :F], db likewise (grad_out NULL = 1/B). */
+int ltr_linear_partials_f32(int kind, float sigma, const float *X, const float *W,
+                            const float *bias, const void *rel, int rel_dtype,
+                            const int64_t *n, int B, int L, int F, float *loss,
+                            float *scores_out, float *partials /* (B, F+1) */, void *stream);
+int ltr_linear_reduce_f32(const float *partials, const float *grad_out, int B, int F, float *dW,
+                          float *db, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LTR_HIP_H */

@@ -1,0 +1,95 @@
+"""ctypes binding of the C ABI in ``include/ltr_hip.h`` (pytorchltr_amd/csrc/libltr_hip.so).
+
+PyTorch supplies device memory and the current HIP stream; every call here hands raw device
+pointers to the library.  The library must exist -- there is deliberately no fallback.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads the HIP runtime the extension binds to, before dlopen)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libltr_hip.so")
+
+# enum ltr_loss_kind
+HINGE, DCG_HINGE, LOGISTIC, ARP1, ARP2, NDCG1, NDCG2 = range(7)
+# enum ltr_label_dtype
+LABEL_I64, LABEL_F32, LABEL_I32 = 0, 1, 2
+
+_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/ltr_hip.h line by line
+SIGNATURES = {
+    "ltr_version": (_i, []),
+    "ltr_error_string": (ctypes.c_char_p, [_i]),
+    "ltr_max_list_len": (_i, []),
+    "ltr_pairwise_loss_f32": (_i, [_i, _f, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
+    "ltr_pairwise_loss_f32_cfg": (_i, [_i, _f, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
+    "ltr_scale_rows_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "ltr_rank_by_score_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "ltr_dcg_f32": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ltr_arp_f32": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
+    "ltr_mask_padded_values_f32": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp]),
+    "ltr_batch_pairs": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "ltr_linear_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ltr_linear_pairwise_f32": (_i, [_i, _f, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i,
+                                     _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ltr_linear_partials_f32": (_i, [_i, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i,
+                                     _vp, _vp, _vp, _vp]),
+    "ltr_linear_reduce_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class ExtensionMissingError(ImportError):
+    pass
+
+
+def lib():
+    """The loaded extension.  Raises loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ExtensionMissingError(
+                "pytorchltr_amd HIP extension not found at %s; build it with "
+                "`python -m pytorchltr_amd.build` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)       # AttributeError if the symbol is missing
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().ltr_error_string(int(rc))
+        raise RuntimeError("pytorchltr_amd: %s (code %d)" % (msg.decode() if msg else "?", rc))
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream_of(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def require_device(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(
+            "pytorchltr_amd: `%s` is on %s; this library only runs its HIP kernels on a ROCm "
+            "device (no CPU fallback). Move the batch with .to('cuda')." % (what, t.device))
+
+
+def label_dtype(rel):
+    if rel.dtype == torch.int64:
+        return LABEL_I64
+    if rel.dtype == torch.float32:
+        return LABEL_F32
+    if rel.dtype == torch.int32:
+        return LABEL_I32
+    raise TypeError("unsupported relevance dtype %s" % rel.dtype)

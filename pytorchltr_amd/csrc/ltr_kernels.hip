@@ -1,0 +1,878 @@
+// ltr_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the pytorchltr
+// ranking-loss / ranking-metric hot path, behind the C ABI of include/ltr_hip.h.
+//
+// Design:
+//   * one workgroup per query; the query's (score, label) row is staged ONCE into LDS,
+//     int64 labels are narrowed to fp32 in registers on the way in;
+//   * the O(n^2) pair expansion of the reference (utils/tensor_operations.py:94-119) is
+//     never materialised: a lane OWNS document(s) k (score, label, accumulators in VGPRs)
+//     and streams every other document m of the query from LDS (wave-uniform address ->
+//     LDS broadcast, conflict-free).  Each unordered pair is visited from both ends, so a
+//     lane accumulates d loss / d s_k without atomics or cross-lane traffic;
+//   * the reference's n-mask (loss/pairwise_additive.py:75-81) is the loop bound m < n[b],
+//     k < n[b]: padded documents are neither loaded nor visited;
+//   * rank positions (Lambda losses, metrics) come from an O(n^2) counting rank in the
+//     same owner/stream structure -- exact, deterministic, no sort network;
+//   * per-query reductions: DPP/shuffle wave reduction + one LDS hop across waves.
+//
+// Written for gfx950 only: wave size 64 is hard-coded.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ltr_hip.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kMaxListLen = 4096;
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+// ---------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float load_label(const void *rel, int dtype, size_t idx)
+{
+    // wave-uniform switch; int64 -> fp32 narrowing happens in registers (no cast kernel)
+    if (dtype == LTR_LABEL_I64) return (float)((const int64_t *)rel)[idx];
+    if (dtype == LTR_LABEL_F32) return ((const float *)rel)[idx];
+    return (float)((const int32_t *)rel)[idx];
+}
+
+__device__ __forceinline__ int clamp_n(int64_t n, int L)
+{
+    return n < 0 ? 0 : (n > (int64_t)L ? L : (int)n);
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+// Sum over the whole workgroup; every thread gets the result.  Deterministic order.
+// `red` is an LDS scratch of >= 16 floats.  Contains barriers: call from uniform code.
+__device__ __forceinline__ float block_sum(float v, float *red)
+{
+    v = wave_sum(v);
+    const int nw = blockDim.x >> 6;
+    if (nw == 1) return v;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+// log2(1 + e) for e in [0, 1]; two-term series below 2^-10 where 1+e would round e away.
+__device__ __forceinline__ float log2_1p(float e)
+{
+    const float direct = __builtin_amdgcn_logf(1.0f + e);      // v_log_f32 == log2
+    const float series = e * (1.0f - 0.5f * e) * kLog2e;
+    return e < 0.0009765625f ? series : direct;
+}
+
+// ---------------------------------------------------------------------------------
+// counting rank: for every owned document k < nb,
+//   rank_s[k] = #{m < nb : s_m > s_k or (s_m == s_k and m < k)}     (score, descending)
+//   rank_y[k] = the same on labels (only if WITH_Y)
+// This is rank_by_score (utils/tensor_operations.py:48-64) restricted to the real
+// documents; padded documents rank at their own index (key -inf, index tie-break).
+// rank arrays must be zeroed by the caller when msplit > 1 (partial counts are added).
+// ---------------------------------------------------------------------------------
+template <int DPT, bool WITH_Y>
+__device__ __forceinline__ void count_ranks(const float2 *sy, int nb, int owners, int o,
+                                            int m0, int m1, bool partial, int *rank_s,
+                                            int *rank_y)
+{
+    for (int base = 0; base < nb; base += owners * DPT) {
+        const int wave_first = base + (o & ~63);
+        if (wave_first >= nb) continue;                       // wave-uniform
+        float sk[DPT], yk[DPT];
+        int cs[DPT], cy[DPT], kk[DPT];
+#pragma unroll
+        for (int c = 0; c < DPT; ++c) {
+            kk[c] = base + o + c * owners;
+            const bool valid = kk[c] < nb;
+            const float2 v = valid ? sy[kk[c]] : make_float2(0.f, 0.f);
+            sk[c] = v.x; yk[c] = v.y; cs[c] = 0; cy[c] = 0;
+        }
+#pragma unroll 4
+        for (int m = m0; m < m1; ++m) {
+            const float2 v = sy[m];
+#pragma unroll
+            for (int c = 0; c < DPT; ++c) {
+                const bool before = m < kk[c];
+                cs[c] += (v.x > sk[c]) | ((v.x == sk[c]) & before);
+                if (WITH_Y) cy[c] += (v.y > yk[c]) | ((v.y == yk[c]) & before);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < DPT; ++c) {
+            if (kk[c] < nb) {
+                if (partial) {
+                    atomicAdd(&rank_s[kk[c]], cs[c]);
+                    if (WITH_Y) atomicAdd(&rank_y[kk[c]], cy[c]);
+                } else {
+                    rank_s[kk[c]] = cs[c];
+                    if (WITH_Y) rank_y[kk[c]] = cy[c];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// pair terms.  Conventions: owner document k (registers), streamed document m (LDS).
+//   c1 = sigma * log2(e)   so that exp(-sigma*d) = exp2(-c1*d)
+// Gradient accumulators are in units of sigma/ln2 (applied once per document at the end).
+// ---------------------------------------------------------------------------------
+
+// Hinge (loss/pairwise_additive.py:107-113): term(i,j) = max(0, 1-(s_i-s_j)) if y_i > y_j.
+// The reference zeroes `loss < 0` (strict), so at exactly the margin the gradient flows.
+__device__ __forceinline__ void pair_hinge(float sk, float yk, float sm, float ym, float &g,
+                                           float &l)
+{
+    const float d = sk - sm;
+    const bool gt = yk > ym, lt = yk < ym;
+    const float u = gt ? (1.0f - d) : (1.0f + d);
+    const bool act = (gt | lt) & (u >= 0.0f);
+    l += (gt & act) ? u : 0.0f;
+    g += act ? (gt ? -1.0f : 1.0f) : 0.0f;
+}
+
+// Logistic / ARP2 / NDCG2: term(i,j) = W_ij * log2(1 + exp(-sigma (s_i - s_j))) if y_i > y_j
+// (loss/pairwise_additive.py:158-163, loss/pairwise_lambda.py:135-140, :198-218), W symmetric.
+// Stable for any finite input (the reference overflows beyond |sigma d| ~ 88).
+__device__ __forceinline__ void pair_oriented(float sk, float yk, float sm, float ym, float W,
+                                              float c1, float &g, float &l)
+{
+    const bool gt = yk > ym, lt = yk < ym;
+    const float t = (sk - sm) * c1;
+    const float z = gt ? t : -t;                       // log2e * sigma * (s_winner - s_loser)
+    const float e = __builtin_amdgcn_exp2f(-fabsf(z));
+    const float r = __builtin_amdgcn_rcpf(1.0f + e);
+    const float psi = (z >= 0.0f) ? e * r : r;         // sigmoid(-sigma (s_win - s_lose))
+    const float lg = log2_1p(e) + fmaxf(-z, 0.0f);     // log2(1 + exp(-sigma (s_win - s_lose)))
+    const float Wm = (gt | lt) ? W : 0.0f;
+    l += gt ? Wm * lg : 0.0f;
+    g += (gt ? -Wm : Wm) * psi;
+}
+
+// ARP1 / NDCG1: term(i,j) = a_i * log2(1 + exp(-sigma (s_i - s_j))) for ALL i, j < n
+// (-log2(sigmoid ** a_i), loss/pairwise_lambda.py:114-117, :165-173).
+__device__ __forceinline__ void pair_rowweight(float sk, float ak, float sm, float am, float c1,
+                                               float &g, float &l)
+{
+    const float t = (sk - sm) * c1;
+    const float e = __builtin_amdgcn_exp2f(-fabsf(t));
+    const float r = __builtin_amdgcn_rcpf(1.0f + e);
+    const float sneg = (t >= 0.0f) ? e * r : r;        // sigmoid(-sigma (s_k - s_m))
+    const float lg = log2_1p(e) + fmaxf(-t, 0.0f);
+    l += ak * lg;
+    g += am - (ak + am) * sneg;                        // -a_k sig(-x) + a_m sig(x)
+}
+
+struct LossParams {
+    const float *scores;
+    const void *rel;
+    const int64_t *n;
+    float *loss;
+    float *dscores;
+    int B, L;
+    float sigma;
+    int rel_dtype;
+    int msplit;
+};
+
+// LDS carve (bytes), L4 = L rounded up to 4:
+//   sy    float2[L4]          (score, label) -- for NDCG1 the label slot is overwritten by a_k
+//   q4    float4[L4]          NDCG2 only: (score, label, gain G, rank)
+//   delta float [L4 + 4]      NDCG2 only: |1/D(d) - 1/D(d+1)|, D(d) = log2(2+d)
+//   gpart float [msplit*L4]   per-slice gradient partials; aliased by the two int rank arrays
+//   red   float [32]
+__host__ __device__ inline size_t loss_lds_bytes(int kind, int L, int msplit)
+{
+    const size_t L4 = (size_t)((L + 3) & ~3);
+    size_t bytes = 8 * L4;
+    if (kind == LTR_NDCG2) bytes += 16 * L4 + 4 * (L4 + 4);
+    size_t g = 4 * L4 * (size_t)msplit;
+    if ((kind == LTR_NDCG1 || kind == LTR_NDCG2) && g < 8 * L4) g = 8 * L4;
+    return bytes + g + 32 * 4;
+}
+
+// LDS views of one query, carved from the dynamic segment (see loss_lds_bytes).
+struct QueryLds {
+    float2 *sy;
+    float4 *q4;
+    float *delta;
+    float *gpart;
+    int *rank_s;
+    int *rank_y;
+    float *red;
+};
+
+template <int KIND>
+__device__ __forceinline__ QueryLds carve_query_lds(unsigned char *base, int L4, int msplit)
+{
+    QueryLds q;
+    q.sy = reinterpret_cast<float2 *>(base);
+    unsigned char *cur = base + 8 * (size_t)L4;
+    q.q4 = nullptr;
+    q.delta = nullptr;
+    if (KIND == LTR_NDCG2) {
+        q.q4 = reinterpret_cast<float4 *>(cur);
+        cur += 16 * (size_t)L4;
+        q.delta = reinterpret_cast<float *>(cur);
+        cur += 4 * (size_t)(L4 + 4);
+    }
+    q.gpart = reinterpret_cast<float *>(cur);
+    q.rank_s = reinterpret_cast<int *>(cur);      // aliases gpart (dead before gpart is written)
+    q.rank_y = q.rank_s + L4;
+    size_t g = 4 * (size_t)L4 * msplit;
+    if ((KIND == LTR_NDCG1 || KIND == LTR_NDCG2) && g < 8 * (size_t)L4) g = 8 * (size_t)L4;
+    cur += g;
+    q.red = reinterpret_cast<float *>(cur);
+    return q;
+}
+
+// The per-query core shared by the loss kernel and the fused scorer kernel.
+// Precondition: q.sy[0..nb) = (score, label) is staged and visible (barrier passed); for the
+// NDCG kinds q.rank_s[0..2*L4) is zeroed.  Postcondition (after the trailing barrier):
+// q.gpart[slice*L4 + k] holds the slice partials of d(pair sum)/d s_k in units of `gscale`;
+// returns the final per-query loss (modifier applied) to every thread.
+template <int KIND, int DPT>
+__device__ __forceinline__ float pairwise_core(const QueryLds &q, int nb, int L4, int msplit,
+                                               float sigma, float &gscale)
+{
+    const int tid = threadIdx.x;
+    const int T = blockDim.x;
+    const int owners = T / msplit;                 // multiple of 64: slices are whole waves
+    const int o = tid % owners;
+    const int slice = tid / owners;
+    float2 *sy = q.sy;
+
+    // slice of the streamed index this thread's wave walks
+    const int mlen = (nb + msplit - 1) / msplit;
+    const int m0 = slice * mlen;
+    const int m1 = min(nb, m0 + mlen);
+    const float c1 = sigma * kLog2e;
+
+    // ---- NDCG kinds: ranks by score and by label, maxDCG, gains ----
+    if (KIND == LTR_NDCG1 || KIND == LTR_NDCG2) {
+        count_ranks<DPT, true>(sy, nb, owners, o, m0, m1, msplit > 1, q.rank_s, q.rank_y);
+        __syncthreads();
+        // _max_dcg (loss/pairwise_lambda.py:231-241): labels sorted descending over the
+        // first n documents, gains 2^y - 1, discounts log2(2 + r).
+        float part = 0.f;
+        for (int k = tid; k < nb; k += T)
+            part += (exp2f(sy[k].y) - 1.0f) / log2f(2.0f + (float)q.rank_y[k]);
+        float maxdcg = block_sum(part, q.red);
+        if (maxdcg == 0.0f) maxdcg = 1.0f;                     // pairwise_lambda.py:227
+        const float inv_maxdcg = 1.0f / maxdcg;
+        for (int k = tid; k < nb; k += T) {
+            const float2 v = sy[k];
+            const float G = (exp2f(v.y) - 1.0f) * inv_maxdcg;   // _ndcg_gains, :221-228
+            const int r = q.rank_s[k];
+            if (KIND == LTR_NDCG1)
+                sy[k].y = G / log2f(2.0f + (float)r);           // a_k = G_k / D(rank_k)
+            else
+                q.q4[k] = make_float4(v.x, v.y, G, (float)r);
+        }
+        if (KIND == LTR_NDCG2)
+            for (int d = tid; d < nb; d += T)                   // delta table, :206-211
+                q.delta[d] = fabsf(1.0f / log2f(2.0f + (float)d) - 1.0f / log2f(3.0f + (float)d));
+        __syncthreads();                                        // ranks dead from here: gpart may be written
+    }
+
+    // ---- pair pass ----
+    float lacc = 0.f;
+    for (int base = 0; base < nb; base += owners * DPT) {
+        const int wave_first = base + (o & ~63);
+        if (wave_first >= nb) continue;                          // wave-uniform
+        float sk[DPT], yk[DPT], Gk[DPT], rk[DPT], gk[DPT];
+        int kk[DPT];
+#pragma unroll
+        for (int c = 0; c < DPT; ++c) {
+            kk[c] = base + o + c * owners;
+            const bool valid = kk[c] < nb;
+            gk[c] = 0.f; Gk[c] = 0.f; rk[c] = 0.f;
+            if (KIND == LTR_NDCG2) {
+                const float4 v = valid ? q.q4[kk[c]] : make_float4(0.f, __builtin_nanf(""), 0.f, 0.f);
+                sk[c] = v.x; yk[c] = v.y; Gk[c] = v.z; rk[c] = v.w;
+            } else if (KIND == LTR_ARP1 || KIND == LTR_NDCG1) {
+                const float2 v = valid ? sy[kk[c]] : make_float2(0.f, 0.f);   // a_k = 0: no loss
+                sk[c] = v.x; yk[c] = v.y;
+            } else {
+                // NaN label: both orientation tests fail -> an idle owner contributes nothing
+                const float2 v = valid ? sy[kk[c]] : make_float2(0.f, __builtin_nanf(""));
+                sk[c] = v.x; yk[c] = v.y;
+            }
+        }
+#pragma unroll 2
+        for (int m = m0; m < m1; ++m) {
+            if (KIND == LTR_NDCG2) {
+                const float4 v = q.q4[m];
+#pragma unroll
+                for (int c = 0; c < DPT; ++c) {
+                    const int d = (int)fabsf(rk[c] - v.w);
+                    const float W = q.delta[d] * fabsf(Gk[c] - v.z);
+                    pair_oriented(sk[c], yk[c], v.x, v.y, W, c1, gk[c], lacc);
+                }
+            } else {
+                const float2 v = sy[m];
+#pragma unroll
+                for (int c = 0; c < DPT; ++c) {
+                    if (KIND == LTR_HINGE || KIND == LTR_DCG_HINGE)
+                        pair_hinge(sk[c], yk[c], v.x, v.y, gk[c], lacc);
+                    else if (KIND == LTR_LOGISTIC)
+                        pair_oriented(sk[c], yk[c], v.x, v.y, 1.0f, c1, gk[c], lacc);
+                    else if (KIND == LTR_ARP2)
+                        pair_oriented(sk[c], yk[c], v.x, v.y, fabsf(yk[c] - v.y), c1, gk[c], lacc);
+                    else
+                        pair_rowweight(sk[c], yk[c], v.x, v.y, c1, gk[c], lacc);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < DPT; ++c)
+            if (kk[c] < nb) q.gpart[(size_t)slice * L4 + kk[c]] = gk[c];
+    }
+
+    // ---- per-query reduction and loss modifier ----
+    float total = block_sum(lacc, q.red);     // its barriers publish gpart when there are >= 2 waves
+    if (T == kWave) __syncthreads();
+    gscale = 1.0f;
+    if (KIND == LTR_DCG_HINGE) {
+        // _loss_modifier (loss/pairwise_additive.py:132-133): -1/ln(2+H);
+        // d/dH = 1/((2+H) ln^2(2+H))
+        const float lg = logf(2.0f + total);
+        gscale = 1.0f / ((2.0f + total) * lg * lg);
+        total = -1.0f / lg;
+    } else if (KIND != LTR_HINGE) {
+        gscale = sigma / kLn2;
+    }
+    return total;
+}
+
+template <int KIND, int DPT>
+__global__ void __launch_bounds__(1024)
+pairwise_loss_kernel(LossParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x;
+    const int L = p.L;
+    const int L4 = (L + 3) & ~3;
+    const int tid = threadIdx.x;
+    const int T = blockDim.x;
+    const int msplit = p.msplit;
+    const int nb = clamp_n(p.n[b], L);
+    const QueryLds q = carve_query_lds<KIND>(smem, L4, msplit);
+
+    // ---- stage the real documents of this query: coalesced 4 B / 8 B per lane ----
+    const size_t row = (size_t)b * L;
+    for (int m = tid; m < nb; m += T)
+        q.sy[m] = make_float2(p.scores[row + m], load_label(p.rel, p.rel_dtype, row + m));
+    if (KIND == LTR_NDCG1 || KIND == LTR_NDCG2)
+        for (int m = tid; m < 2 * L4; m += T) q.rank_s[m] = 0;
+    __syncthreads();
+
+    float gscale;
+    const float total = pairwise_core<KIND, DPT>(q, nb, L4, msplit, p.sigma, gscale);
+
+    if (tid == 0) p.loss[b] = total;
+    if (p.dscores != nullptr) {
+        for (int k = tid; k < L; k += T) {
+            float g = 0.f;
+            if (k < nb) {
+                for (int s = 0; s < msplit; ++s) g += q.gpart[(size_t)s * L4 + k];
+                g *= gscale;
+            }
+            p.dscores[row + k] = g;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// backward: out[b, j] = grad_out[b] * dscores[b, j]
+// ---------------------------------------------------------------------------------
+__global__ void scale_rows_kernel(const float *__restrict__ ds, const float *__restrict__ go,
+                                  size_t total, int L, float *__restrict__ out)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
+        out[i] = ds[i] * go[i / (size_t)L];
+}
+
+__global__ void scale_rows_vec4_kernel(const float4 *__restrict__ ds, const float *__restrict__ go,
+                                       size_t total4, int L4, float4 *__restrict__ out)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+        const float g = go[i / (size_t)L4];
+        float4 v = ds[i];
+        v.x *= g; v.y *= g; v.z *= g; v.w *= g;
+        out[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// rank_by_score / dcg / ndcg / arp
+// ---------------------------------------------------------------------------------
+struct MetricParams {
+    const float *scores;
+    const void *rel;
+    const int64_t *n;
+    void *out;
+    int B, L;
+    int rel_dtype;
+    int k;           // dcg: cutoff (0 = full curve)
+    int use_exp;
+    int normalize;
+    int msplit;
+};
+
+__host__ __device__ inline size_t metric_lds_bytes(int L)
+{
+    const size_t L4 = (size_t)((L + 3) & ~3);
+    return 8 * L4 + 8 * L4 + 8 * L4 + 32 * 4 + 64 * 4;   // sy, ranks, two curves, red, scan
+}
+
+// Inclusive prefix sum of buf[0..L) in place (LDS).  Thread t owns a contiguous chunk.
+__device__ void block_inclusive_scan(float *buf, int L, float *scan_scratch)
+{
+    const int T = blockDim.x, tid = threadIdx.x;
+    const int ch = (L + T - 1) / T;
+    const int lo = min(L, tid * ch), hi = min(L, lo + ch);
+    float s = 0.f;
+    for (int i = lo; i < hi; ++i) s += buf[i];
+    // exclusive scan of per-thread sums: wave scan + cross-wave offsets
+    float incl = s;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const float up = __shfl_up(incl, off, kWave);
+        if ((tid & 63) >= off) incl += up;
+    }
+    const int w = tid >> 6, nw = T >> 6;
+    __syncthreads();
+    if ((tid & 63) == 63) scan_scratch[w] = incl;
+    __syncthreads();
+    float woff = 0.f;
+    for (int i = 0; i < w; ++i) woff += scan_scratch[i];
+    (void)nw;
+    float run = woff + incl - s;
+    for (int i = lo; i < hi; ++i) { run += buf[i]; buf[i] = run; }
+    __syncthreads();
+}
+
+enum { METRIC_RANK = 0, METRIC_DCG = 1, METRIC_ARP = 2 };
+
+template <int OP, int DPT>
+__global__ void __launch_bounds__(1024)
+metric_kernel(MetricParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x;
+    const int L = p.L;
+    const int L4 = (L + 3) & ~3;
+    const int tid = threadIdx.x;
+    const int T = blockDim.x;
+    const int msplit = p.msplit;
+    const int owners = T / msplit;
+    const int o = tid % owners;
+    const int slice = tid / owners;
+    const int nb = clamp_n(p.n[b], L);
+
+    float2 *sy = reinterpret_cast<float2 *>(smem);
+    int *rank_s = reinterpret_cast<int *>(smem + 8 * (size_t)L4);
+    int *rank_y = rank_s + L4;
+    float *curve = reinterpret_cast<float *>(smem + 16 * (size_t)L4);
+    float *icurve = curve + L4;
+    float *red = icurve + L4;
+    float *scan_scratch = red + 32;
+
+    const size_t row = (size_t)b * L;
+    const bool need_labels = (OP != METRIC_RANK);
+    // dcg keeps the reference's quirk: padded labels are read and counted (dcg.py:85-94)
+    const int nload = (OP == METRIC_DCG) ? L : nb;
+    for (int m = tid; m < nload; m += T)
+        sy[m] = make_float2(p.scores[row + m],
+                            need_labels ? load_label(p.rel, p.rel_dtype, row + m) : 0.f);
+    for (int m = tid; m < 2 * L4; m += T) rank_s[m] = 0;
+    __syncthreads();
+
+    const int mlen = (nb + msplit - 1) / msplit;
+    const int m0 = slice * mlen;
+    const int m1 = min(nb, m0 + mlen);
+    const bool with_y = (OP == METRIC_DCG) && p.normalize;
+    if (with_y)
+        count_ranks<DPT, true>(sy, nb, owners, o, m0, m1, msplit > 1, rank_s, rank_y);
+    else
+        count_ranks<DPT, false>(sy, nb, owners, o, m0, m1, msplit > 1, rank_s, rank_y);
+    __syncthreads();
+
+    if (OP == METRIC_RANK) {
+        // invert: ranking[rank_k] = k; padded documents keep their index (tail in index order)
+        int *inv = rank_y;
+        for (int k = tid; k < L; k += T) inv[k < nb ? rank_s[k] : k] = k;
+        __syncthreads();
+        int64_t *out = reinterpret_cast<int64_t *>(p.out) + row;
+        for (int r = tid; r < L; r += T) out[r] = (int64_t)inv[r];
+        return;
+    }
+
+    if (OP == METRIC_ARP) {
+        // arp.py:31-42: sum((r+1) * rel_r) / sum(rel_r) over ranks r < n; 0 -> 1 guard
+        float srp = 0.f, nrp = 0.f;
+        for (int k = tid; k < nb; k += T) {
+            const float y = sy[k].y;
+            srp += (float)(rank_s[k] + 1) * y;
+            nrp += y;
+        }
+        srp = block_sum(srp, red);
+        nrp = block_sum(nrp, red);
+        if (nrp == 0.0f) nrp = 1.0f;
+        if (tid == 0) reinterpret_cast<float *>(p.out)[b] = srp / nrp;
+        return;
+    }
+
+    // ---- dcg / ndcg ----
+    const int kk = p.k > 0 ? min(p.k, L) : 0;
+    float part = 0.f, ipart = 0.f;
+    for (int k = tid; k < L; k += T) {
+        const float y = sy[k].y;
+        const float gain = p.use_exp ? (exp2f(y) - 1.0f) : y;        // dcg.py:91-92
+        const int r = k < nb ? rank_s[k] : k;
+        const float term = gain / log2f((float)r + 2.0f);             // dcg.py:93
+        int ry = 0;
+        float iterm = 0.f;
+        if (p.normalize) {
+            ry = k < nb ? rank_y[k] : k;                              // ideal ranking, dcg.py:36
+            iterm = gain / log2f((float)ry + 2.0f);
+        }
+        if (kk > 0) {
+            part += (r < kk) ? term : 0.f;
+            ipart += (p.normalize && ry < kk) ? iterm : 0.f;
+        } else {
+            curve[r] = term;
+            if (p.normalize) icurve[ry] = iterm;
+        }
+    }
+    if (kk > 0) {
+        part = block_sum(part, red);
+        if (p.normalize) {
+            ipart = block_sum(ipart, red);
+            if (ipart == 0.0f) ipart = 1.0f;                           // dcg.py:37
+            part = part / ipart;
+        }
+        if (tid == 0) reinterpret_cast<float *>(p.out)[b] = part;
+        return;
+    }
+    __syncthreads();
+    block_inclusive_scan(curve, L, scan_scratch);                      // cumsum, dcg.py:94
+    if (p.normalize) block_inclusive_scan(icurve, L, scan_scratch);
+    float *out = reinterpret_cast<float *>(p.out) + row;
+    for (int r = tid; r < L; r += T) {
+        float v = curve[r];
+        if (p.normalize) {
+            float id = icurve[r];
+            if (id == 0.0f) id = 1.0f;
+            v /= id;
+        }
+        out[r] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// mask_padded_values / batch_pairs
+// ---------------------------------------------------------------------------------
+__global__ void mask_padded_kernel(const float *__restrict__ xs, const int64_t *__restrict__ n,
+                                   size_t total, int L, float mask_value, float *__restrict__ out)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const size_t b = i / (size_t)L;
+        const int j = (int)(i - b * (size_t)L);
+        out[i] = ((int64_t)j >= n[b]) ? mask_value : xs[i];
+    }
+}
+
+// out[b,i,j,0] = x[b,i]; out[b,i,j,1] = x[b,j].  One (i,j) pair per thread-iteration,
+// written as a single 2-element vector store (8 B or 16 B per lane, coalesced along j).
+template <typename T, typename T2>
+__global__ void batch_pairs_kernel(const T *__restrict__ x, int L, T2 *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const T *xr = x + (size_t)b * L;
+    T2 *o = out + (size_t)b * L * L;
+    const size_t LL = (size_t)L * L;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < LL; e += stride) {
+        const int i = (int)(e / (size_t)L);
+        const int j = (int)(e - (size_t)i * L);
+        T2 v;
+        v.x = xr[i];
+        v.y = xr[j];
+        o[e] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// host side: launch-shape heuristic and dispatch
+// ---------------------------------------------------------------------------------
+constexpr size_t kLdsBudget = 160 * 1024;
+// Raise a kernel's dynamic-LDS limit above the 64 KiB default once per device (the attribute is
+// sticky), so steady-state launches -- including hipGraph capture -- issue no extra API calls.
+constexpr int kMaxDevices = 64;
+#define LTR_ENSURE_LDS(KERNEL, BYTES)                                                           \
+    do {                                                                                        \
+        static size_t cfg_[kMaxDevices] = {};                                                   \
+        int dev_ = 0;                                                                           \
+        (void)hipGetDevice(&dev_);                                                              \
+        if ((size_t)(BYTES) > 64 * 1024 && dev_ >= 0 && dev_ < kMaxDevices &&                   \
+            (size_t)(BYTES) > cfg_[dev_]) {                                                     \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL),        \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                                (int)kLdsBudget);                               \
+            if (e_ != hipSuccess) return (int)e_;                                               \
+            cfg_[dev_] = kLdsBudget;                                                            \
+        }                                                                                       \
+    } while (0)
+
+struct LaunchShape { int owners, dpt, msplit; };
+
+LaunchShape choose_shape(int B, int L)
+{
+    LaunchShape s;
+    if (L <= 64) { s.owners = 64; s.dpt = 1; }
+    else if (L <= 128) { s.owners = 128; s.dpt = 1; }
+    else if (L <= 256) { s.owners = 256; s.dpt = 1; }
+    else if (L <= 512) { s.owners = 256; s.dpt = 2; }
+    else { s.owners = 256; s.dpt = 4; }
+    // Split the streamed index over more waves while the grid would leave SIMDs empty:
+    // 256 CUs x 4 SIMDs, aim for >= 4 waves per SIMD.
+    s.msplit = 1;
+    const long target_waves = 4096;
+    while ((long)B * (s.owners / 64) * s.msplit < target_waves && s.owners * s.msplit * 2 <= 1024 &&
+           (L / (s.msplit * 2)) >= 16)
+        s.msplit *= 2;
+    return s;
+}
+
+template <int KIND>
+int launch_loss_kind(const LossParams &p, const LaunchShape &s, hipStream_t stream)
+{
+    const dim3 grid((unsigned)p.B), block((unsigned)(s.owners * s.msplit));
+    const size_t lds = loss_lds_bytes(KIND, p.L, s.msplit);
+#define LTR_LAUNCH(D)                                                                           \
+    do {                                                                                        \
+        LTR_ENSURE_LDS((pairwise_loss_kernel<KIND, D>), lds);          \
+        hipLaunchKernelGGL((pairwise_loss_kernel<KIND, D>), grid, block, lds, stream, p);       \
+    } while (0)
+    switch (s.dpt) {
+    case 1: LTR_LAUNCH(1); break;
+    case 2: LTR_LAUNCH(2); break;
+    case 4: LTR_LAUNCH(4); break;
+    default: return LTR_ERR_CONFIG;
+    }
+#undef LTR_LAUNCH
+    return (int)hipGetLastError();
+}
+
+int launch_loss(int kind, const LossParams &p, const LaunchShape &s, hipStream_t stream)
+{
+    switch (kind) {
+    case LTR_HINGE: return launch_loss_kind<LTR_HINGE>(p, s, stream);
+    case LTR_DCG_HINGE: return launch_loss_kind<LTR_DCG_HINGE>(p, s, stream);
+    case LTR_LOGISTIC: return launch_loss_kind<LTR_LOGISTIC>(p, s, stream);
+    case LTR_ARP1: return launch_loss_kind<LTR_ARP1>(p, s, stream);
+    case LTR_ARP2: return launch_loss_kind<LTR_ARP2>(p, s, stream);
+    case LTR_NDCG1: return launch_loss_kind<LTR_NDCG1>(p, s, stream);
+    case LTR_NDCG2: return launch_loss_kind<LTR_NDCG2>(p, s, stream);
+    default: return LTR_ERR_KIND;
+    }
+}
+
+template <int OP>
+int launch_metric(const MetricParams &p0, hipStream_t stream)
+{
+    MetricParams p = p0;
+    LaunchShape s = choose_shape(p.B, p.L);
+    p.msplit = s.msplit;
+    const dim3 grid((unsigned)p.B), block((unsigned)(s.owners * s.msplit));
+    const size_t lds = metric_lds_bytes(p.L);
+#define LTR_LAUNCH(D)                                                                           \
+    do {                                                                                        \
+        LTR_ENSURE_LDS((metric_kernel<OP, D>), lds);          \
+        hipLaunchKernelGGL((metric_kernel<OP, D>), grid, block, lds, stream, p);                \
+    } while (0)
+    switch (s.dpt) {
+    case 1: LTR_LAUNCH(1); break;
+    case 2: LTR_LAUNCH(2); break;
+    default: LTR_LAUNCH(4); break;
+    }
+#undef LTR_LAUNCH
+    return (int)hipGetLastError();
+}
+
+inline bool bad_label_dtype(int d) { return d != LTR_LABEL_I64 && d != LTR_LABEL_F32 && d != LTR_LABEL_I32; }
+
+inline unsigned grid_for(size_t items, int block)
+{
+    size_t g = (items + (size_t)block - 1) / (size_t)block;
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;          // 256 CUs x 8 blocks, grid-stride the rest
+    return (unsigned)g;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------
+extern "C" {
+
+int ltr_version(void) { return LTR_VERSION; }
+
+int ltr_max_list_len(void) { return kMaxListLen; }
+
+const char *ltr_error_string(int code)
+{
+    switch (code) {
+    case LTR_OK: return "ok";
+    case LTR_ERR_NULL: return "ltr: required pointer is NULL";
+    case LTR_ERR_SHAPE: return "ltr: invalid shape (need B >= 0, L > 0, F > 0, k >= 0)";
+    case LTR_ERR_KIND: return "ltr: unknown loss kind or label dtype";
+    case LTR_ERR_LIST_TOO_LONG: return "ltr: list_len exceeds ltr_max_list_len()";
+    case LTR_ERR_WORKSPACE: return "ltr: workspace missing or too small";
+    case LTR_ERR_CONFIG: return "ltr: invalid explicit launch configuration";
+    default: break;
+    }
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "ltr: unknown error";
+}
+
+int ltr_pairwise_loss_f32_cfg(int kind, float sigma, const float *scores, const void *rel,
+                              int rel_dtype, const int64_t *n, int B, int L, float *loss,
+                              float *dscores, int owners, int dpt, int msplit, void *stream)
+{
+    if (kind < LTR_HINGE || kind > LTR_NDCG2 || bad_label_dtype(rel_dtype)) return LTR_ERR_KIND;
+    if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
+    if (L > kMaxListLen) return LTR_ERR_LIST_TOO_LONG;
+    if (B == 0) return LTR_OK;
+    if (!scores || !rel || !n || !loss) return LTR_ERR_NULL;
+    if (owners <= 0 || owners % 64 != 0 || msplit <= 0 || owners * msplit > 1024 ||
+        (dpt != 1 && dpt != 2 && dpt != 4) || loss_lds_bytes(kind, L, msplit) > kLdsBudget)
+        return LTR_ERR_CONFIG;
+    LossParams p;
+    p.scores = scores; p.rel = rel; p.n = n; p.loss = loss; p.dscores = dscores;
+    p.B = B; p.L = L; p.sigma = sigma; p.rel_dtype = rel_dtype; p.msplit = msplit;
+    LaunchShape s{owners, dpt, msplit};
+    return launch_loss(kind, p, s, (hipStream_t)stream);
+}
+
+int ltr_pairwise_loss_f32(int kind, float sigma, const float *scores, const void *rel,
+                          int rel_dtype, const int64_t *n, int B, int L, float *loss,
+                          float *dscores, void *stream)
+{
+    if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
+    LaunchShape s = choose_shape(B, L);
+    while (s.msplit > 1 && loss_lds_bytes(kind, L, s.msplit) > kLdsBudget) s.msplit /= 2;
+    return ltr_pairwise_loss_f32_cfg(kind, sigma, scores, rel, rel_dtype, n, B, L, loss, dscores,
+                                     s.owners, s.dpt, s.msplit, stream);
+}
+
+int ltr_scale_rows_f32(const float *dscores, const float *grad_out, int B, int L, float *out,
+                       void *stream)
+{
+    if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
+    if (B == 0) return LTR_OK;
+    if (!dscores || !grad_out || !out) return LTR_ERR_NULL;
+    const size_t total = (size_t)B * L;
+    const bool vec = (L % 4 == 0) && (((uintptr_t)dscores | (uintptr_t)out) % 16 == 0);
+    if (vec)
+        hipLaunchKernelGGL(scale_rows_vec4_kernel, dim3(grid_for(total / 4, 256)), dim3(256), 0,
+                           (hipStream_t)stream, (const float4 *)dscores, grad_out, total / 4, L / 4,
+                           (float4 *)out);
+    else
+        hipLaunchKernelGGL(scale_rows_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
+                           (hipStream_t)stream, dscores, grad_out, total, L, out);
+    return (int)hipGetLastError();
+}
+
+int ltr_rank_by_score_f32(const float *scores, const int64_t *n, int B, int L, int64_t *ranking,
+                          void *stream)
+{
+    if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
+    if (L > kMaxListLen) return LTR_ERR_LIST_TOO_LONG;
+    if (B == 0) return LTR_OK;
+    if (!scores || !n || !ranking) return LTR_ERR_NULL;
+    MetricParams p{};
+    p.scores = scores; p.rel = nullptr; p.n = n; p.out = ranking; p.B = B; p.L = L;
+    return launch_metric<METRIC_RANK>(p, (hipStream_t)stream);
+}
+
+int ltr_dcg_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n, int B,
+                int L, int k, int use_exp, int normalize, float *out, void *stream)
+{
+    if (bad_label_dtype(rel_dtype)) return LTR_ERR_KIND;
+    if (B < 0 || L <= 0 || k < 0) return LTR_ERR_SHAPE;
+    if (L > kMaxListLen) return LTR_ERR_LIST_TOO_LONG;
+    if (B == 0) return LTR_OK;
+    if (!scores || !rel || !n || !out) return LTR_ERR_NULL;
+    MetricParams p{};
+    p.scores = scores; p.rel = rel; p.n = n; p.out = out; p.B = B; p.L = L;
+    p.rel_dtype = rel_dtype; p.k = k; p.use_exp = use_exp; p.normalize = normalize;
+    return launch_metric<METRIC_DCG>(p, (hipStream_t)stream);
+}
+
+int ltr_arp_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n, int B,
+                int L, float *out, void *stream)
+{
+    if (bad_label_dtype(rel_dtype)) return LTR_ERR_KIND;
+    if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
+    if (L > kMaxListLen) return LTR_ERR_LIST_TOO_LONG;
+    if (B == 0) return LTR_OK;
+    if (!scores || !rel || !n || !out) return LTR_ERR_NULL;
+    MetricParams p{};
+    p.scores = scores; p.rel = rel; p.n = n; p.out = out; p.B = B; p.L = L;
+    p.rel_dtype = rel_dtype;
+    return launch_metric<METRIC_ARP>(p, (hipStream_t)stream);
+}
+
+int ltr_mask_padded_values_f32(const float *xs, const int64_t *n, int B, int L, float mask_value,
+                               float *out, void *stream)
+{
+    if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
+    if (B == 0) return LTR_OK;
+    if (!xs || !n || !out) return LTR_ERR_NULL;
+    const size_t total = (size_t)B * L;
+    hipLaunchKernelGGL(mask_padded_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, xs, n, total, L, mask_value, out);
+    return (int)hipGetLastError();
+}
+
+int ltr_batch_pairs(const void *x, int elem_bytes, int B, int L, void *out, void *stream)
+{
+    if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
+    if (elem_bytes != 4 && elem_bytes != 8) return LTR_ERR_KIND;
+    if (B == 0) return LTR_OK;
+    if (!x || !out) return LTR_ERR_NULL;
+    if (B > 65535) return LTR_ERR_SHAPE;
+    const size_t LL = (size_t)L * L;
+    unsigned gx = grid_for(LL, 256);
+    if (elem_bytes == 4)
+        hipLaunchKernelGGL((batch_pairs_kernel<uint32_t, uint2>), dim3(gx, (unsigned)B), dim3(256), 0,
+                           (hipStream_t)stream, (const uint32_t *)x, L, (uint2 *)out);
+    else
+        hipLaunchKernelGGL((batch_pairs_kernel<uint64_t, ulonglong2>), dim3(gx, (unsigned)B),
+                           dim3(256), 0, (hipStream_t)stream, (const uint64_t *)x, L,
+                           (ulonglong2 *)out);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"
+
+#include "ltr_linear.inc"

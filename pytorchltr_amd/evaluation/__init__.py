@@ -1,0 +1,4 @@
+"""Ranking metrics -- same names as pytorchltr/evaluation/__init__.py:1-3."""
+from pytorchltr_amd.evaluation.arp import arp  # noqa: F401
+from pytorchltr_amd.evaluation.dcg import ndcg  # noqa: F401
+from pytorchltr_amd.evaluation.dcg import dcg  # noqa: F401

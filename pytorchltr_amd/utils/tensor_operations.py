@@ -1,0 +1,98 @@
+"""L1 helpers of the hot path on MI355X (reference: utils/tensor_operations.py).
+
+The losses and metrics never call these (their kernels fuse masking, ranking and the pair
+expansion); they are provided because the reference exports them.
+"""
+from typing import Optional
+
+import torch as _torch
+
+from pytorchltr_amd import _C
+from pytorchltr_amd._prepare import as_2d as _as_2d
+from pytorchltr_amd._prepare import prepare_n as _prepare_n
+from pytorchltr_amd._prepare import prepare_scores as _prepare_scores
+
+
+def mask_padded_values(xs: _torch.FloatTensor, n: _torch.LongTensor,
+                       mask_value: float = -float('inf'),
+                       mutate: bool = False):
+    """Sets entries j >= n[b] of every row to `mask_value` (reference :6-26).
+
+    With mutate=True, `xs` (fp32, contiguous) is overwritten in place and returned."""
+    _C.require_device(xs, "xs")
+    x2 = _as_2d(xs, "xs")
+    nn = _prepare_n(n, x2.shape[0])
+    B, L = x2.shape
+    if mutate:
+        if xs.dtype != _torch.float32 or not xs.is_contiguous():
+            raise TypeError("mutate=True needs a contiguous float32 tensor")
+        src, out = x2, x2
+    else:
+        src = _prepare_scores(xs)
+        out = _torch.empty_like(src)
+    if B > 0 and L > 0:
+        with _torch.cuda.device(src.device):
+            _C.check(_C.lib().ltr_mask_padded_values_f32(
+                _C.ptr(src), _C.ptr(nn), B, L, float(mask_value), _C.ptr(out),
+                _C.stream_of(src)))
+    if mutate:
+        return xs
+    out = out.reshape(xs.shape)
+    return out if xs.dtype == _torch.float32 else out.to(xs.dtype)
+
+
+def _rank(scores2d, nn):
+    B, L = scores2d.shape
+    ranking = _torch.empty(B, L, dtype=_torch.int64, device=scores2d.device)
+    if B > 0:
+        with _torch.cuda.device(scores2d.device):
+            _C.check(_C.lib().ltr_rank_by_score_f32(
+                _C.ptr(scores2d), _C.ptr(nn), B, L, _C.ptr(ranking), _C.stream_of(scores2d)))
+    return ranking
+
+
+def tiebreak_argsort(
+        x: _torch.FloatTensor,
+        descending: bool = True,
+        generator: Optional[_torch.Generator] = None) -> _torch.LongTensor:
+    """Per-row argsort (reference :29-45).
+
+    Deviation: ties are broken by column index (deterministic) instead of a random
+    permutation; `generator` is accepted for signature compatibility and ignored."""
+    s = _prepare_scores(x)
+    if not descending:
+        s = -s
+    nn = _torch.full((s.shape[0],), s.shape[1], dtype=_torch.int64, device=s.device)
+    return _rank(s, nn)
+
+
+def rank_by_score(
+        scores: _torch.FloatTensor,
+        n: _torch.LongTensor,
+        generator: Optional[_torch.Generator] = None) -> _torch.LongTensor:
+    """Indices that sort each row by decreasing score, padded documents last (reference
+    :48-64).  Ties by index; the padded tail comes out in index order."""
+    s = _prepare_scores(scores)
+    nn = _prepare_n(n, s.shape[0])
+    max_l = _C.lib().ltr_max_list_len()
+    if s.shape[1] > max_l:
+        raise ValueError("list_size %d exceeds the supported maximum %d" % (s.shape[1], max_l))
+    return _rank(s, nn)
+
+
+def batch_pairs(x: _torch.Tensor) -> _torch.Tensor:
+    """Materialises all pairs: p[b,i,j,0] = x[b,i], p[b,i,j,1] = x[b,j] (reference :94-119).
+
+    Returns a (batch, list_size, list_size, 2) tensor of x's dtype (4- or 8-byte dtypes)."""
+    _C.require_device(x, "x")
+    x2 = _as_2d(x, "x").contiguous()
+    B, L = x2.shape
+    esize = x2.element_size()
+    if esize not in (4, 8):
+        raise TypeError("batch_pairs supports 4- and 8-byte dtypes, got %s" % x2.dtype)
+    out = _torch.empty(B, L, L, 2, dtype=x2.dtype, device=x2.device)
+    if B > 0 and L > 0:
+        with _torch.cuda.device(x2.device):
+            _C.check(_C.lib().ltr_batch_pairs(_C.ptr(x2), esize, B, L, _C.ptr(out),
+                                              _C.stream_of(x2)))
+    return out

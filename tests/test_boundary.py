@@ -1,0 +1,172 @@
+"""CPU tier: the drop-in boundary.  The C-ABI library loads and exports every symbol that
+include/ltr_hip.h declares; the Python surface mirrors the reference's names and signatures;
+the product never touches the oracle; CPU tensors are refused (no fallback).  No HIP compute
+is launched here."""
+import ast
+import ctypes
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ltr_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ltr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported_and_bound():
+    from pytorchltr_amd import _C
+    from pytorchltr_amd.build import build_extension
+    build_extension()
+    declared = _declared_symbols()
+    assert len(declared) >= 15
+    handle = ctypes.CDLL(_C.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), "libltr_hip.so does not export %s" % name
+    # the ctypes table covers exactly the header
+    assert sorted(_C.SIGNATURES) == declared
+    lib = _C.lib()
+    assert lib.ltr_version() == 100
+    assert lib.ltr_max_list_len() >= 1024
+    assert b"NULL" in lib.ltr_error_string(-1)
+    assert lib.ltr_linear_workspace_bytes(1024, 128, 136) >= 1024 * 137 * 4
+
+
+def test_argument_validation_without_a_gpu():
+    """Argument errors are decided on the host before any launch."""
+    from pytorchltr_amd import _C
+    lib = _C.lib()
+    assert lib.ltr_pairwise_loss_f32(99, 1.0, None, None, 0, None, 1, 8, None, None, None) == -3
+    assert lib.ltr_pairwise_loss_f32(0, 1.0, None, None, 7, None, 1, 8, None, None, None) == -3
+    assert lib.ltr_pairwise_loss_f32(0, 1.0, None, None, 0, None, -1, 8, None, None, None) == -2
+    assert lib.ltr_pairwise_loss_f32(0, 1.0, None, None, 0, None, 1, 0, None, None, None) == -2
+    assert lib.ltr_pairwise_loss_f32(0, 1.0, None, None, 0, None, 1, 100000, None, None, None) == -4
+    assert lib.ltr_pairwise_loss_f32(0, 1.0, None, None, 0, None, 1, 8, None, None, None) == -1
+    assert lib.ltr_pairwise_loss_f32(0, 1.0, None, None, 0, None, 0, 8, None, None, None) == 0
+    assert lib.ltr_pairwise_loss_f32_cfg(0, 1.0, 1, 1, 0, 1, 1, 8, 1, None, 96, 1, 1, None) == -6
+    assert lib.ltr_pairwise_loss_f32_cfg(0, 1.0, 1, 1, 0, 1, 1, 8, 1, None, 64, 3, 1, None) == -6
+    assert lib.ltr_dcg_f32(None, None, 0, None, 1, 8, -1, 1, 0, None, None) == -2
+    assert lib.ltr_batch_pairs(None, 2, 1, 8, None, None) == -3
+    assert lib.ltr_linear_pairwise_f32(0, 1.0, 1, 1, 1, 1, 0, 1, None, 4, 8, 4, 1, None, 1, 1,
+                                       None, 0, None) == -5
+    with pytest.raises(RuntimeError, match="list_len"):
+        _C.check(-4)
+
+
+def test_python_surface_mirrors_reference_signatures():
+    import pytorchltr_amd.evaluation as ev
+    import pytorchltr_amd.loss as losses
+    import pytorchltr_amd.utils as utils
+    # pytorchltr/loss/__init__.py:1-7
+    for name in ("PairwiseHingeLoss", "PairwiseDCGHingeLoss", "PairwiseLogisticLoss",
+                 "LambdaARPLoss1", "LambdaARPLoss2", "LambdaNDCGLoss1", "LambdaNDCGLoss2"):
+        cls = getattr(losses, name)
+        assert issubclass(cls, torch.nn.Module)
+        assert list(inspect.signature(cls.forward).parameters) == ["self", "scores", "relevance", "n"]
+        assert len(cls().state_dict()) == 0            # parameter-free, checkpoints interchangeable
+    assert issubclass(losses.PairwiseDCGHingeLoss, losses.PairwiseHingeLoss)
+    assert losses.PairwiseLogisticLoss(sigma=2.0).sigma == 2.0
+    assert losses.LambdaNDCGLoss2().sigma == 1.0
+    assert [p.default for p in inspect.signature(losses.PairwiseLogisticLoss.__init__).parameters.values()][1] == 1.0
+    # pytorchltr/evaluation/__init__.py:1-3, evaluation/dcg.py:8-10,41-43, arp.py:7-8
+    for fn in (ev.dcg, ev.ndcg):
+        sig = inspect.signature(fn)
+        assert list(sig.parameters) == ["scores", "relevance", "n", "k", "exp"]
+        assert sig.parameters["k"].default is None and sig.parameters["exp"].default is True
+    assert list(inspect.signature(ev.arp).parameters) == ["scores", "relevance", "n"]
+    # pytorchltr/utils/tensor_operations.py:6-8,29-32,48-51,94
+    sig = inspect.signature(utils.mask_padded_values)
+    assert list(sig.parameters) == ["xs", "n", "mask_value", "mutate"]
+    assert sig.parameters["mask_value"].default == -float("inf") and sig.parameters["mutate"].default is False
+    assert list(inspect.signature(utils.tiebreak_argsort).parameters) == ["x", "descending", "generator"]
+    assert list(inspect.signature(utils.rank_by_score).parameters) == ["scores", "n", "generator"]
+    assert list(inspect.signature(utils.batch_pairs).parameters) == ["x"]
+
+
+def test_cpu_tensors_are_refused_not_silently_computed():
+    import pytorchltr_amd.evaluation as ev
+    import pytorchltr_amd.loss as losses
+    from pytorchltr_amd.utils import batch_pairs, rank_by_score
+    s = torch.zeros(2, 4)
+    y = torch.zeros(2, 4, dtype=torch.int64)
+    n = torch.tensor([4, 2])
+    for call in (lambda: losses.PairwiseHingeLoss()(s, y, n), lambda: losses.LambdaNDCGLoss2()(s, y, n),
+                 lambda: ev.ndcg(s, y, n, k=10), lambda: ev.arp(s, y, n),
+                 lambda: rank_by_score(s, n), lambda: batch_pairs(s)):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            call()
+
+
+def test_missing_extension_fails_loudly(monkeypatch):
+    from pytorchltr_amd import _C
+    monkeypatch.setattr(_C, "_lib", None)
+    monkeypatch.setattr(_C, "LIB_PATH", os.path.join(ROOT, "pytorchltr_amd", "csrc", "nope.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _C.lib()
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use oracle/."""
+    pkg = os.path.join(ROOT, "pytorchltr_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            tree = ast.parse(open(os.path.join(dirpath, f)).read())
+            for node in ast.walk(tree):
+                mods = []
+                if isinstance(node, ast.Import):
+                    mods = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    mods = [node.module or ""]
+                for m in mods:
+                    assert not m.split(".")[0] == "oracle", "%s imports %s" % (f, m)
+            assert "/root/reference" not in open(os.path.join(dirpath, f)).read()
+    for f in ("bench.py", "__graft_entry__.py"):
+        assert "/root/reference" not in open(os.path.join(ROOT, f)).read()
+
+
+def test_cutoff_semantics_follow_python_slicing():
+    from pytorchltr_amd.evaluation.dcg import _cutoff
+    assert _cutoff(None, 10) == 0            # full curve
+    assert _cutoff(3, 10) == 3
+    assert _cutoff(50, 10) == 10             # k > L silently means DCG@L (reference dcg.py:97-98)
+    assert _cutoff(-2, 10) == 8              # dcg[:, :-2][:, -1]
+    with pytest.raises(IndexError):
+        _cutoff(0, 10)
+    with pytest.raises(IndexError):
+        _cutoff(-10, 10)
+
+
+def test_prepare_shapes_and_dtypes_host_logic(monkeypatch):
+    """Shape/dtype normalisation, exercised with the device check stubbed out."""
+    from pytorchltr_amd import _C, _prepare
+    monkeypatch.setattr(_C, "require_device", lambda t, what: None)
+    s = torch.zeros(3, 5, 1, dtype=torch.float64)
+    y = torch.zeros(3, 5, 1, dtype=torch.int16)
+    n = torch.tensor([5, 2, 0], dtype=torch.int32)
+    s2, y2, n2 = _prepare.prepare(s, y, n)
+    assert s2.shape == (3, 5) and s2.dtype == torch.float32 and s2.is_contiguous()
+    assert y2.shape == (3, 5) and y2.dtype == torch.float32
+    assert n2.dtype == torch.int64
+    with pytest.raises(ValueError):
+        _prepare.prepare(torch.zeros(3, 5, 2), y, n)
+    with pytest.raises(ValueError):
+        _prepare.prepare(torch.zeros(3, 5), torch.zeros(3, 4), n)
+    with pytest.raises(ValueError):
+        _prepare.prepare(torch.zeros(3, 5), torch.zeros(3, 5), torch.tensor([1, 2]))
+    with pytest.raises(TypeError):
+        _prepare.prepare(torch.zeros(3, 5, dtype=torch.int64), torch.zeros(3, 5), n)
+    with pytest.raises(TypeError):
+        _prepare.prepare(torch.zeros(3, 5), torch.zeros(3, 5), torch.tensor([1.0, 2.0, 3.0]))
+    with pytest.raises(ValueError):
+        _prepare.prepare(torch.zeros(1, 5000), torch.zeros(1, 5000), torch.tensor([1]))
+    assert _C.label_dtype(torch.zeros(1, dtype=torch.int64)) == _C.LABEL_I64
+    assert _C.label_dtype(torch.zeros(1, dtype=torch.int32)) == _C.LABEL_I32
+    assert _C.label_dtype(torch.zeros(1)) == _C.LABEL_F32

@@ -1,0 +1,149 @@
+"""GPU parity of the fused Linear(F,1)+loss kernel and of the drop-in training loop."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ltr_oracle as O
+from tests.conftest import load_golden, synth
+
+pytestmark = pytest.mark.gpu
+G = load_golden()
+KINDS = list(O.KINDS)
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _check(kind, B, L, F, seed, sigma=1.0, full=False, grad_out=None):
+    from pytorchltr_amd.fused import linear_loss_step
+    dev = _dev()
+    s, y, n, X, W, b = synth(B, L, seed, F=F)
+    if full:
+        n = torch.full_like(n, L)
+    from pytorchltr_amd import loss as L_
+    mod = {"hinge": L_.PairwiseHingeLoss, "dcg_hinge": L_.PairwiseDCGHingeLoss,
+           "logistic": L_.PairwiseLogisticLoss, "arp1": L_.LambdaARPLoss1,
+           "arp2": L_.LambdaARPLoss2, "ndcg1": L_.LambdaNDCGLoss1, "ndcg2": L_.LambdaNDCGLoss2}[kind]
+    loss_mod = mod() if kind in ("hinge", "dcg_hinge") else mod(sigma)
+    go = None if grad_out is None else grad_out.to(dev)
+    loss, dW, db, scores = linear_loss_step(X.to(dev), W.to(dev), b.to(dev), y.to(dev), n.to(dev),
+                                            loss=loss_mod, grad_out=go, return_scores=True)
+    gout = np.full(B, 1.0 / B) if grad_out is None else grad_out.numpy().astype(np.float64)
+    want_l, want_s, want_dW, want_db = O.linear_pairwise(kind, X.numpy(), W.numpy(), float(b[0]),
+                                                         y.numpy(), n.numpy(), gout, sigma=sigma)
+    assert np.allclose(scores.cpu().numpy(), want_s, rtol=1e-5, atol=1e-5)
+    rtol = 5e-4 if L > 256 else 2e-5
+    assert np.allclose(loss.cpu().numpy(), want_l, rtol=rtol, atol=1e-5), kind
+    tol = 2e-5 * max(1.0, float(np.max(np.abs(want_dW)))) * (10 if L > 256 else 1)
+    assert np.max(np.abs(dW.cpu().numpy() - want_dW)) < tol, kind
+    assert abs(float(db.cpu()[0]) - want_db) < tol, kind
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_fused_step_small_shapes(kind):
+    _check(kind, 8, 16, 5, 1234)                 # scalar path (F % 4 != 0), Example3-like F
+    _check(kind, 6, 37, 12, 5, sigma=2.0)        # vector path, odd L
+    _check(kind, 5, 64, 136, 6)                  # C2 feature width
+
+
+@pytest.mark.parametrize("kind", ["hinge", "logistic", "ndcg2"])
+def test_fused_step_c2_shape(kind):
+    _check(kind, 32, 128, 136, 3)
+    _check(kind, 16, 128, 136, 4, full=True)
+    _check(kind, 16, 128, 136, 4, grad_out=torch.linspace(-0.5, 1.5, 16))
+
+
+@pytest.mark.parametrize("shape", [(6, 1000, 220, "dcg_hinge"), (6, 512, 700, "hinge"),
+                                   (4, 300, 64, "ndcg1"), (3, 2000, 16, "arp2")])
+def test_fused_step_large_tiles(shape):
+    B, L, F, kind = shape
+    _check(kind, B, L, F, 8)                     # tile does not fit LDS: re-read path
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in G.by_op("linear_step")])
+def test_fused_step_vs_reference_vectors(name):
+    """Against what the real reference computed for loss_fn(Linear(X), y, n).mean().backward()."""
+    from pytorchltr_amd.fused import linear_loss_step
+    dev = _dev()
+    case = G.cases[name]
+    X, W, b = (torch.as_tensor(G.get(name, f)).to(dev) for f in ("X", "W", "b"))
+    y, n = (torch.as_tensor(G.get(name, f)).to(dev) for f in ("relevance", "n"))
+    for kind in case["kinds"]:
+        loss, dW, db, scores = linear_loss_step(X, W, b, y, n, loss=kind, return_scores=True)
+        assert np.allclose(scores.cpu().numpy(), G.get(name, kind + "/scores"), rtol=1e-5, atol=1e-5)
+        assert np.allclose(loss.cpu().numpy(), G.get(name, kind + "/loss"), rtol=2e-5, atol=1e-5), kind
+        ref_dW = G.get(name, kind + "/dW")
+        tol = 3e-5 * max(1.0, float(np.max(np.abs(ref_dW))))
+        assert np.max(np.abs(dW.cpu().numpy() - ref_dW)) < tol, kind
+        assert abs(float(db.cpu()[0]) - float(G.get(name, kind + "/db")[0])) < tol, kind
+
+
+def test_fused_module_matches_unfused_dropin():
+    """FusedLinearLoss == loss_fn(nn.Linear(F,1)(xs), ys, n) for arbitrary upstream weights."""
+    from pytorchltr_amd.fused import FusedLinearLoss
+    from pytorchltr_amd.loss import LambdaNDCGLoss2
+    dev = _dev()
+    s, y, n, X, W, b = synth(24, 50, 11, F=20)
+    lin = torch.nn.Linear(20, 1).to(dev)
+    fused = FusedLinearLoss(20, LambdaNDCGLoss2(sigma=0.7)).to(dev)
+    fused.load_state_dict(lin.state_dict())                   # state_dict compatible with nn.Linear
+    w = torch.rand(24, device=dev)
+    (LambdaNDCGLoss2(sigma=0.7)(lin(X.to(dev)), y.to(dev), n.to(dev)) * w).sum().backward()
+    out, sc = fused(X.to(dev), y.to(dev), n.to(dev), return_scores=True)
+    (out * w).sum().backward()
+    assert torch.allclose(sc, lin(X.to(dev)).reshape(24, 50).detach(), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(fused.weight.grad, lin.weight.grad, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(fused.bias.grad, lin.bias.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_example3_training_trace():
+    """BASELINE.json configs[0]: examples/01-basic-usage.py on the Example3 toy data.  Linear(5,1),
+    PairwiseHingeLoss, SGD lr 0.1, batch 2; published trace: test nDCG@10 0.8617 at start."""
+    from pytorchltr_amd.evaluation import ndcg
+    from pytorchltr_amd.loss import PairwiseHingeLoss
+    dev = _dev()
+    name = "c1_example3_step"
+    X, W, b = (torch.as_tensor(G.get(name, f)).to(dev) for f in ("X", "W", "b"))
+    y, n = (torch.as_tensor(G.get(name, f)).to(dev) for f in ("relevance", "n"))
+    model = torch.nn.Linear(5, 1).to(dev)
+    with torch.no_grad():
+        model.weight.copy_(W.reshape(1, 5))
+        model.bias.copy_(b)
+    loss = PairwiseHingeLoss()(model(X), y, n)
+    assert loss.detach().cpu().numpy() == pytest.approx([4.6077, 1.0157], abs=2e-4)
+    loss.mean().backward()
+    assert model.weight.grad.cpu().numpy().reshape(-1) == pytest.approx(
+        [-2.5, 0.0, 0.0, 0.16667, -1.0], abs=1e-4)
+    assert float(model.bias.grad.cpu()) == pytest.approx(0.0, abs=1e-6)
+    s, yt, nt = (torch.as_tensor(a).to(dev) for a in G.inputs("c1_example3_eval"))
+    assert float(ndcg(s, yt, nt, k=10).cpu()) == pytest.approx(0.8617, abs=1e-4)
+
+
+def test_sgd_learning_improves_arp():
+    """The reference's only end-to-end test (tests/test_integration.py:18-63): SGD on a linear
+    scorer with PairwiseHingeLoss must reduce ARP substantially.  Synthetic separable data."""
+    from pytorchltr_amd.evaluation import arp
+    from pytorchltr_amd.loss import PairwiseHingeLoss
+    dev = _dev()
+    torch.manual_seed(42)
+    g = torch.Generator().manual_seed(42)
+    B, L, F = 16, 30, 8
+    X = torch.randn(B, L, F, generator=g)
+    true_w = torch.randn(F, generator=g)
+    y = ((X @ true_w) > 0.5).long() + ((X @ true_w) > 1.5).long()
+    n = torch.randint(10, L + 1, (B,), generator=g)
+    X, y, n = X.to(dev), y.to(dev), n.to(dev)
+    model = torch.nn.Linear(F, 1).to(dev)
+    opt = torch.optim.SGD(model.parameters(), lr=0.01)
+    loss_fn = PairwiseHingeLoss()
+    with torch.no_grad():
+        start = float(arp(model(X), y, n).mean())
+    for _ in range(100):
+        opt.zero_grad()
+        loss_fn(model(X), y, n).mean().backward()
+        opt.step()
+    with torch.no_grad():
+        end = float(arp(model(X), y, n).mean())
+    assert end - start <= -0.40

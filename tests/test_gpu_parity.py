@@ -1,0 +1,322 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP kernels, called through the C ABI,
+against the CPU oracle (fp64) and the golden vectors captured from the real reference.
+
+Stated tolerances (measured spread of the reference's own fp32 vs fp64 runs):
+  loss      rtol 1e-5 for list_len <= 256, 5e-4 above, atol 2e-6
+  gradient  |err| <= 1e-5 * max|grad_row| + 1e-6; hinge gradients bit-exact (integers)
+  rankings  bit-exact on the first n[b] entries of tie-free rows; tail = permutation of n..L-1
+  metrics   rtol 2e-6 (list_len <= 256) / 2e-5 above, atol 1e-6
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ltr_oracle as O
+from tests.conftest import load_golden, synth
+
+pytestmark = pytest.mark.gpu
+
+G = load_golden()
+KINDS = list(O.KINDS)
+RANK_FREE = {"hinge", "dcg_hinge", "logistic", "arp1", "arp2"}
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tier needs a ROCm device"
+    return torch.device("cuda:0")
+
+
+def _loss_tol(L):
+    return (5e-4 if L > 256 else 1e-5), 2e-6
+
+
+def _check_loss(got, want, L, what):
+    rtol, atol = _loss_tol(L)
+    got = np.asarray(got, dtype=np.float64)
+    assert np.all(np.isfinite(got)), what
+    err = np.abs(got - want) - (atol + rtol * np.abs(want))
+    assert np.all(err <= 0), "%s: loss mismatch, worst excess %.3e" % (what, err.max())
+
+
+def _check_grad(got, want, what, exact=False):
+    got = np.asarray(got, dtype=np.float64).reshape(want.shape)
+    if exact:
+        assert np.array_equal(got, want), what
+        return
+    scale = np.max(np.abs(want), axis=1, keepdims=True)
+    err = np.abs(got - want) - (1e-5 * scale + 1e-6)
+    assert np.all(err <= 0), "%s: grad mismatch, worst excess %.3e" % (what, err.max())
+
+
+def _run_direct(kind, s, y, n, sigma=1.0, cfg=None):
+    from pytorchltr_amd import _C
+    from pytorchltr_amd._autograd import pairwise_loss_and_grad
+    dev = _dev()
+    loss, ds = pairwise_loss_and_grad(torch.as_tensor(s).to(dev), torch.as_tensor(y).to(dev),
+                                      torch.as_tensor(n).to(dev), _C.__dict__[kind.upper()],
+                                      sigma, cfg=cfg)
+    return loss.cpu().numpy(), ds.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in G.by_op("loss")])
+def test_losses_vs_oracle_and_reference_vectors(name):
+    case = G.cases[name]
+    s, y, n = G.inputs(name)
+    L = s.shape[1]
+    for kind in case["kinds"]:
+        loss, ds = _run_direct(kind, s, y, n, case["sigma"])
+        want_l, want_g = O.pairwise_loss(kind, s, y, n, sigma=case["sigma"])
+        _check_loss(loss, want_l, L, "%s/%s vs oracle" % (name, kind))
+        _check_grad(ds, want_g, "%s/%s vs oracle" % (name, kind), exact=(kind == "hinge"))
+        # and directly against what the real reference returned (fp32 run)
+        _check_loss(loss, G.get(name, kind + "/loss32").astype(np.float64), L,
+                    "%s/%s vs reference" % (name, kind))
+        if case["tie_free"] or kind in RANK_FREE:
+            ref_g = G.get(name, kind + "/grad32").astype(np.float64).reshape(want_g.shape)
+            _check_grad(ds, ref_g, "%s/%s vs reference" % (name, kind), exact=(kind == "hinge"))
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in G.by_op("loss") if "literal" in c])
+def test_reference_unit_test_literals(name):
+    case = G.cases[name]
+    s, y, n = G.inputs(name)
+    for kind, expected in case["literal"].items():
+        loss, _ = _run_direct(kind, s, y, n, case["sigma"])
+        assert loss == pytest.approx(np.asarray(expected), rel=1e-5, abs=2e-6), kind
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_module_autograd_path_mean_backward(kind):
+    """The drop-in call of the reference's training loop:
+    loss_fn(scores, relevance, n).mean().backward()  (examples/01-basic-usage.py:72-75)."""
+    import pytorchltr_amd.loss as losses
+    cls = {"hinge": losses.PairwiseHingeLoss, "dcg_hinge": losses.PairwiseDCGHingeLoss,
+           "logistic": losses.PairwiseLogisticLoss, "arp1": losses.LambdaARPLoss1,
+           "arp2": losses.LambdaARPLoss2, "ndcg1": losses.LambdaNDCGLoss1,
+           "ndcg2": losses.LambdaNDCGLoss2}[kind]
+    dev = _dev()
+    s, y, n = synth(32, 48, 5)
+    for shape3d in (False, True):
+        sc = (s.reshape(32, 48, 1) if shape3d else s).clone().to(dev).requires_grad_(True)
+        loss_fn = cls() if kind in ("hinge", "dcg_hinge") else cls(sigma=1.5)
+        sigma = 1.0 if kind in ("hinge", "dcg_hinge") else 1.5
+        out = loss_fn(sc, y.to(dev), n.to(dev))
+        assert out.shape == (32,) and out.dtype == torch.float32
+        out.mean().backward()
+        assert sc.grad.shape == sc.shape
+        want_l, want_g = O.pairwise_loss(kind, s.numpy(), y.numpy(), n.numpy(), sigma=sigma)
+        _check_loss(out.detach().cpu().numpy(), want_l, 48, kind)
+        _check_grad(sc.grad.cpu().numpy().reshape(32, 48) * 32.0, want_g, kind, exact=False)
+    # no-grad forward takes the forward-only path and agrees
+    with torch.no_grad():
+        out2 = loss_fn(s.to(dev), y.to(dev), n.to(dev))
+    assert torch.allclose(out2, out.detach(), rtol=0, atol=0)
+    # weighted reduction: arbitrary upstream gradient per query
+    sc = s.clone().to(dev).requires_grad_(True)
+    w = torch.linspace(-1.0, 2.0, 32, device=dev)
+    (loss_fn(sc, y.to(dev), n.to(dev)) * w).sum().backward()
+    _check_grad(sc.grad.cpu().numpy(), want_g * w.cpu().numpy()[:, None].astype(np.float64), kind)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("cfg", [(64, 1, 1), (64, 2, 1), (64, 4, 1), (128, 1, 2), (128, 2, 4),
+                                 (256, 4, 4), (256, 1, 1), (512, 2, 2), (1024, 1, 1)])
+def test_launch_shapes_agree(kind, cfg):
+    """Every (owners, documents-per-thread, split) launch shape computes the same thing."""
+    s, y, n = synth(12, 200, 9)
+    n[0] = 200
+    n[1] = 1
+    n[2] = 0
+    loss, ds = _run_direct(kind, s.numpy(), y.numpy(), n.numpy(), 1.0, cfg=cfg)
+    want_l, want_g = O.pairwise_loss(kind, s.numpy(), y.numpy(), n.numpy())
+    _check_loss(loss, want_l, 200, "%s %s" % (kind, cfg))
+    _check_grad(ds, want_g, "%s %s" % (kind, cfg), exact=(kind == "hinge"))
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in G.by_op("metrics")])
+def test_metrics_vs_oracle_and_reference_vectors(name):
+    import pytorchltr_amd.evaluation as ev
+    from pytorchltr_amd.utils import rank_by_score
+    dev = _dev()
+    case = G.cases[name]
+    s, y, n = G.inputs(name)
+    L = s.shape[1]
+    rtol = 2e-5 if L > 256 else 2e-6
+    ts, ty, tn = (torch.as_tensor(a).to(dev) for a in (s, y, n))
+    ranking = rank_by_score(ts, tn).cpu().numpy()
+    assert ranking.dtype == np.int64
+    assert np.array_equal(ranking, O.rank_by_score(s, n))                 # bit-exact vs oracle
+    nn = np.clip(n, 0, L)
+    ref_rank = G.get(name, "ranking")
+    for b in range(s.shape[0]):
+        if case["tie_free"]:
+            assert np.array_equal(ranking[b, :nn[b]], ref_rank[b, :nn[b]])
+        assert sorted(ranking[b, nn[b]:].tolist()) == list(range(nn[b], L))
+    got = ev.arp(ts, ty, tn).cpu().numpy()
+    assert np.allclose(got, O.arp(s, y, n), rtol=rtol, atol=1e-6)
+    assert np.allclose(got, G.get(name, "arp"), rtol=rtol, atol=1e-6)
+    for k in case["ks"]:
+        for exp in (True, False):
+            tag = "k%s_%s" % ("all" if k is None else k, "exp" if exp else "lin")
+            d = ev.dcg(ts, ty, tn, k=k, exp=exp).cpu().numpy()
+            nd = ev.ndcg(ts, ty, tn, k=k, exp=exp).cpu().numpy()
+            assert d.shape == G.get(name, "dcg_" + tag).shape
+            assert np.allclose(d, O.dcg(s, y, n, k=k, exp=exp), rtol=rtol, atol=1e-6), tag
+            assert np.allclose(nd, O.ndcg(s, y, n, k=k, exp=exp), rtol=rtol, atol=1e-6), tag
+            assert np.allclose(d, G.get(name, "dcg_" + tag), rtol=rtol, atol=1e-6), tag
+            assert np.allclose(nd, G.get(name, "ndcg_" + tag), rtol=rtol, atol=1e-6), tag
+
+
+def test_helpers_vs_reference_vectors():
+    from pytorchltr_amd.utils import batch_pairs, mask_padded_values, tiebreak_argsort
+    dev = _dev()
+    s = torch.as_tensor(G.get("helpers", "scores")).to(dev)
+    y = torch.as_tensor(G.get("helpers", "relevance")).to(dev)
+    n = torch.as_tensor(G.get("helpers", "n")).to(dev)
+    assert np.array_equal(mask_padded_values(s, n).cpu().numpy(), G.get("helpers", "mask_default"))
+    assert np.array_equal(mask_padded_values(s, n, mask_value=0.0).cpu().numpy(),
+                          G.get("helpers", "mask_zero"))
+    s2 = s.clone()
+    assert mask_padded_values(s2, n, mask_value=0.0, mutate=True) is s2
+    assert np.array_equal(s2.cpu().numpy(), G.get("helpers", "mask_zero"))
+    assert np.array_equal(s.cpu().numpy(), G.get("helpers", "scores"))     # input untouched
+    assert np.array_equal(batch_pairs(s).cpu().numpy(), G.get("helpers", "pairs_scores"))
+    p = batch_pairs(y)
+    assert p.dtype == torch.int64
+    assert np.array_equal(p.cpu().numpy(), G.get("helpers", "pairs_relevance"))
+    a = tiebreak_argsort(s).cpu().numpy()
+    assert np.array_equal(a, np.argsort(-G.get("helpers", "scores"), axis=1, kind="stable"))
+    a = tiebreak_argsort(s, descending=False).cpu().numpy()
+    assert np.array_equal(a, np.argsort(G.get("helpers", "scores"), axis=1, kind="stable"))
+
+
+def test_ties_follow_the_documented_rule():
+    """Ties: score descending, then index ascending -- identical to the oracle."""
+    from pytorchltr_amd.utils import rank_by_score
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    s = torch.randint(0, 4, (16, 50), generator=g).float()              # many ties
+    y = torch.randint(0, 3, (16, 50), generator=g)
+    n = torch.randint(0, 51, (16,), generator=g)
+    r = rank_by_score(s.to(dev), n.to(dev)).cpu().numpy()
+    assert np.array_equal(r, O.rank_by_score(s.numpy(), n.numpy()))
+    for kind in KINDS:
+        loss, ds = _run_direct(kind, s.numpy(), y.numpy(), n.numpy())
+        want_l, want_g = O.pairwise_loss(kind, s.numpy(), y.numpy(), n.numpy())
+        _check_loss(loss, want_l, 50, kind)
+        _check_grad(ds, want_g, kind, exact=(kind == "hinge"))
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE.json full sizes: oracle on a slice of rows + size-independent properties
+# ---------------------------------------------------------------------------------------
+FULL = [("C2", 1024, 128, ["hinge", "logistic", "ndcg2"]),
+        ("C3", 1024, 128, ["ndcg2", "arp1", "ndcg1"]),
+        ("C4", 256, 1000, ["dcg_hinge", "ndcg2"]),
+        ("C5", 512, 512, ["hinge", "arp2"])]
+
+
+@pytest.mark.parametrize("cfg", FULL, ids=[f[0] for f in FULL])
+def test_full_size_configs(cfg):
+    _, B, L, kinds = cfg
+    dev = _dev()
+    s, y, n = synth(B, L, 0)
+    rows = np.r_[0:6, B - 2:B]
+    for kind in kinds:
+        loss, ds = _run_direct(kind, s.numpy(), y.numpy(), n.numpy())
+        assert np.all(np.isfinite(loss)) and np.all(np.isfinite(ds))
+        want_l, want_g = O.pairwise_loss(kind, s.numpy()[rows], y.numpy()[rows], n.numpy()[rows])
+        _check_loss(loss[rows], want_l, L, kind)
+        _check_grad(ds[rows], want_g, kind, exact=(kind == "hinge"))
+        nn = n.numpy()
+        # property: gradients vanish on padded documents, and sum to 0 over a query
+        # (every loss is a function of score differences only)
+        mask = np.arange(L)[None, :] >= nn[:, None]
+        assert np.all(ds[mask] == 0.0)
+        scale = np.abs(ds).sum(axis=1) + 1e-6
+        assert np.all(np.abs(ds.sum(axis=1)) <= 2e-5 * scale)
+        # property: the n-mask -- garbage in padded slots changes nothing (bit-exact)
+        s2, y2 = s.clone(), y.clone()
+        pad = torch.as_tensor(mask)
+        s2[pad] = 1e6
+        y2[pad] = 7
+        loss2, ds2 = _run_direct(kind, s2.numpy(), y2.numpy(), nn)
+        assert np.array_equal(loss, loss2) and np.array_equal(ds, ds2)
+        # property: permuting the real documents of a query permutes the gradient and keeps the
+        # loss (up to summation order)
+        perm = torch.stack([torch.cat([torch.randperm(int(k)), torch.arange(int(k), L)]) for k in nn])
+        s3 = torch.gather(s, 1, perm)
+        y3 = torch.gather(y, 1, perm)
+        loss3, ds3 = _run_direct(kind, s3.numpy(), y3.numpy(), nn)
+        rtol, atol = _loss_tol(L)
+        assert np.allclose(loss3, loss, rtol=10 * rtol, atol=10 * atol)
+        back = np.take_along_axis(ds, perm.numpy(), axis=1)
+        gs = np.max(np.abs(back), axis=1, keepdims=True)
+        ok = np.abs(ds3 - back) <= 2e-4 * gs + 1e-5
+        if kind in ("ndcg1", "ndcg2"):
+            # rank-dependent losses: the index tie-break is not permutation invariant, so
+            # only rows whose real scores are tie-free are comparable
+            tie_free = np.array([len(np.unique(s.numpy()[b, :nn[b]])) == nn[b] for b in range(B)])
+            assert tie_free.sum() > B // 2
+            ok = ok[tie_free]
+        assert np.all(ok)
+
+
+def test_full_size_metrics_c3():
+    import pytorchltr_amd.evaluation as ev
+    from pytorchltr_amd.utils import rank_by_score
+    dev = _dev()
+    s, y, n = synth(1024, 128, 0)
+    y = y * (torch.arange(128)[None, :] < n[:, None])
+    ts, ty, tn = s.to(dev), y.to(dev), n.to(dev)
+    r = rank_by_score(ts, tn).cpu().numpy()
+    assert np.array_equal(r, O.rank_by_score(s.numpy(), n.numpy()))
+    # sortedness property on every row
+    srt = np.take_along_axis(s.numpy(), r, axis=1)
+    for b in range(1024):
+        k = int(n[b])
+        assert np.all(np.diff(srt[b, :k]) <= 0)
+    got = ev.ndcg(ts, ty, tn, k=10).cpu().numpy()
+    assert np.allclose(got, O.ndcg(s.numpy(), y.numpy(), n.numpy(), k=10), rtol=2e-6, atol=1e-6)
+    assert np.all((got >= 0) & (got <= 1 + 1e-6))
+    # ndcg of the ideal ordering is 1 wherever a relevant document exists
+    ideal = ev.ndcg(ty.float(), ty, tn, k=10).cpu().numpy()
+    has_rel = (y.numpy().sum(axis=1) > 0)
+    assert np.allclose(ideal[has_rel], 1.0, atol=1e-6)
+    curve = ev.dcg(ts, ty, tn).cpu().numpy()
+    assert np.all(np.diff(curve, axis=1) >= -1e-6)                  # cumulative
+    assert np.allclose(curve[:, 9], ev.dcg(ts, ty, tn, k=10).cpu().numpy(), rtol=2e-6, atol=1e-6)
+    a = ev.arp(ts, ty, tn).cpu().numpy()
+    assert np.allclose(a, O.arp(s.numpy(), y.numpy(), n.numpy()), rtol=2e-6, atol=1e-6)
+
+
+def test_large_scores_stay_finite():
+    """Outside the reference's finite domain (|sigma d| > 88 gives inf/NaN there) the kernels
+    use a stable softplus: finite loss, gradients bounded by the pair weights."""
+    s = np.array([[0.0, 500.0, -500.0, 90.0, -90.0]], dtype=np.float32)
+    y = np.array([[2, 0, 1, 1, 0]], dtype=np.int64)
+    n = np.array([5], dtype=np.int64)
+    for kind in KINDS:
+        loss, ds = _run_direct(kind, s, y, n)
+        assert np.all(np.isfinite(loss)) and np.all(np.isfinite(ds)), kind
+        want_l, want_g = O.pairwise_loss(kind, s, y, n)
+        if np.all(np.isfinite(want_l)):
+            _check_loss(loss, want_l, 5, kind)
+
+
+def test_argument_errors_are_loud():
+    import pytorchltr_amd.loss as losses
+    dev = _dev()
+    s, y, n = synth(4, 8, 1)
+    with pytest.raises(RuntimeError):
+        losses.PairwiseHingeLoss()(s, y, n)                          # CPU tensors: no fallback
+    with pytest.raises(ValueError):
+        losses.PairwiseHingeLoss()(s.to(dev), y[:, :4].to(dev), n.to(dev))
+    with pytest.raises(ValueError):
+        losses.PairwiseHingeLoss()(s.to(dev), y.to(dev), n[:2].to(dev))
+    out = losses.PairwiseHingeLoss()(s.to(dev)[:0], y.to(dev)[:0], n.to(dev)[:0])
+    assert out.shape == (0,)
+    # int32 n and float labels are accepted, like the reference
+    a = losses.LambdaNDCGLoss2()(s.to(dev), y.to(dev), n.to(dev))
+    b = losses.LambdaNDCGLoss2()(s.to(dev), y.float().to(dev), n.int().to(dev))
+    assert torch.equal(a, b)
