@@ -58,8 +58,9 @@ def synth(B, L, F, seed, device):
 
 
 def time_events(fn, iters):
-    """Average per-launch duration (us) of fn() with one HIP event pair per launch, recorded
-    on the stream the kernels are launched on (torch's current stream)."""
+    """Per-launch duration (us) of fn() with ONE HIP event pair per launch, on the stream the
+    kernels are launched on (torch's current stream).  Includes the event-record overhead
+    (~4-5 us on this stack), so it is an upper bound; see time_launches for the figure used."""
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
     torch.cuda.synchronize()
@@ -70,6 +71,28 @@ def time_events(fn, iters):
     torch.cuda.synchronize()
     per = sorted(s.elapsed_time(e) * 1e3 for s, e in zip(starts, ends))
     return sum(per) / len(per), per[len(per) // 2], per[0]
+
+
+def time_launches(fn, per_graph=20, replays=10):
+    """Average launch duration (us): `per_graph` back-to-back launches of fn() captured into a
+    hipGraph, replayed `replays` times between ONE HIP event pair on the launch stream; the
+    average therefore contains the kernel plus its dependent-launch boundary, not host or event
+    overhead.  Falls back to eager back-to-back launches if capture is unavailable."""
+    def many():
+        for _ in range(per_graph):
+            fn()
+    replay = try_graph(many, warm=1)
+    run = replay if replay is not None else many
+    run()
+    torch.cuda.synchronize()
+    start = torch.cuda.Event(enable_timing=True)
+    end = torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(replays):
+        run()
+    end.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(end) * 1e3 / (per_graph * replays), replay is not None
 
 
 def time_wall(fn, steps, barrier):
@@ -109,17 +132,27 @@ def try_graph(step, warm=3):
 def cpu_baseline(kind, B, L, F, reps=5):
     """The reference-equivalent CPU path (materialising torch port) on this box's cores."""
     from oracle import materialized_torch as M
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     _, relevance, n, X = synth(B, L, F, 0, "cpu")
     lin = torch.nn.Linear(F, 1)
-    M.linear_step(kind, X, lin.weight, lin.bias, relevance, n)          # warm-up
-    ts = []
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        M.linear_step(kind, X, lin.weight, lin.bias, relevance, n)
-        ts.append(time.perf_counter() - t0)
-    med = sorted(ts)[len(ts) // 2]
+    # The port is memory-copy bound; over-subscribing a many-core host makes it slower, so
+    # report the BEST of a small thread sweep (the reference user would tune this too).
+    best = None
+    for threads in sorted({min(8, ncpu), min(32, ncpu), min(64, ncpu), ncpu}):
+        torch.set_num_threads(threads)
+        M.linear_step(kind, X, lin.weight, lin.bias, relevance, n)      # warm-up
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            M.linear_step(kind, X, lin.weight, lin.bias, relevance, n)
+            ts.append(time.perf_counter() - t0)
+            if ts[-1] > 3.0:
+                break
+        med = sorted(ts)[len(ts) // 2]
+        if best is None or med < best[0]:
+            best = (med, threads)
+    med, cores = best
+    torch.set_num_threads(cores)
     scores = torch.randn(B, L)
     M.loss_step(kind, scores, relevance, n)
     t0 = time.perf_counter()
@@ -133,8 +166,9 @@ def cpu_baseline(kind, B, L, F, reps=5):
     return {
         "value": B / med, "unit": "queries/s", "cores": cores, "kind": "port",
         "sample": "median of %d full steps (Linear(%d,1)+%s fwd+bwd, B=%d, L=%d) of "
-                  "oracle/materialized_torch.py, %d torch threads" % (reps, F, kind, B, L, cores),
-        "ms_per_step": med * 1e3,
+                  "oracle/materialized_torch.py; best of a torch-thread sweep on %d host CPUs = %d "
+                  "threads" % (reps, F, kind, B, L, ncpu, cores),
+        "ms_per_step": med * 1e3, "host_cpus": ncpu,
         "loss_only_queries_per_s": B / loss_only,
         "c_oracle_scalar_1core_queries_per_s": B / c_scalar,
     }
@@ -228,7 +262,7 @@ def main():
         W = fused.weight.detach().reshape(F).contiguous()
         bvec = fused.bias.detach().reshape(1).contiguous()
         lossv = torch.empty(B, device=dev)
-        part = torch.empty(B, F + 1, device=dev)
+        part = torch.empty(F + 1, B, device=dev)
         stream = torch.cuda.current_stream().cuda_stream
 
         def launch_fused():
@@ -239,7 +273,8 @@ def main():
 
         for _ in range(10):
             launch_fused()
-        k_avg, k_med, k_min = time_events(launch_fused, 100)
+        k_evt_avg, k_evt_med, k_evt_min = time_events(launch_fused, 100)
+        k_avg, k_graphed = time_launches(launch_fused)
         # algorithmic bytes per query of the fused step: features 4LF read
         # once + labels 8L + n 8 + W/bias 4(F+1) amortised per launch + loss 4 + partials 4(F+1)
         alg_bytes = B * (4 * L * F + 8 * L + 8 + 4 + 4 * (F + 1)) + 4 * (F + 1)
@@ -252,7 +287,9 @@ def main():
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "kernel": "linear_pairwise_kernel<%s>" % kind,
-                    "kernel_us_avg": k_avg, "kernel_us_median": k_med, "kernel_us_min": k_min,
+                    "kernel_us_avg": k_avg,
+                    "timing": "HIP events around %s back-to-back launches" % ("hipGraph-replayed" if k_graphed else "eager"),
+                    "kernel_us_single_launch_event_pair": {"avg": k_evt_avg, "median": k_evt_med, "min": k_evt_min},
                     "algorithmic_bytes_per_launch": alg_bytes}
 
         # ---- loss-only drop-in path (the literal "loss fwd+bwd" of the metric) ----
@@ -285,10 +322,11 @@ def main():
 
         for _ in range(10):
             launch_loss()
-        l_avg, l_med, l_min = time_events(launch_loss, 100)
+        l_evt_avg, l_evt_med, l_evt_min = time_events(launch_loss, 100)
+        l_avg, _ = time_launches(launch_loss)
         loss_bytes = B * (16 * L + 16)
         extra["loss_kernel"] = {"kernel": "pairwise_loss_kernel<%s>" % kind, "us_avg": l_avg,
-                                "us_median": l_med, "us_min": l_min,
+                                "us_single_launch_event_pair": {"avg": l_evt_avg, "median": l_evt_med, "min": l_evt_min},
                                 "algorithmic_bytes_per_launch": loss_bytes,
                                 "achieved_GBs": loss_bytes / (l_avg * 1e-6) / 1e9,
                                 "frac_of_hbm_peak": loss_bytes / (l_avg * 1e-6) / 1e9 / HBM_PEAK_GBS}

@@ -143,12 +143,13 @@ int ltr_linear_pairwise_f32(int kind, float sigma, const float *X, const float *
                             void *workspace, size_t workspace_bytes, void *stream);
 
 /* The same step split at the autograd boundary (forward / backward of a fused
- * Linear+loss module): partials[b, 0..F) = d loss[b] / dW, partials[b, F] = d loss[b] / d bias,
- * then dW = sum_b grad_out[b] * partials[b, :F], db likewise (grad_out NULL = 1/B). */
+ * Linear+loss module): partials is (F+1, B) row-major -- partials[f, b] = d loss[b] / dW_f for
+ * f < F, partials[F, b] = d loss[b] / d bias -- so that the reduction over queries reads
+ * contiguously; then dW_f = sum_b grad_out[b] * partials[f, b], db likewise (grad_out NULL = 1/B). */
 int ltr_linear_partials_f32(int kind, float sigma, const float *X, const float *W,
                             const float *bias, const void *rel, int rel_dtype,
                             const int64_t *n, int B, int L, int F, float *loss,
-                            float *scores_out, float *partials /* (B, F+1) */, void *stream);
+                            float *scores_out, float *partials /* (F+1, B) */, void *stream);
 int ltr_linear_reduce_f32(const float *partials, const float *grad_out, int B, int F, float *dW,
                           float *db, void *stream);
 

@@ -39,6 +39,31 @@ __device__ __forceinline__ float load_label(const void *rel, int dtype, size_t i
     return (float)((const int32_t *)rel)[idx];
 }
 
+// Stage one query's (score, label) pairs into LDS.  The label-dtype switch is hoisted out of
+// the loop (wave-uniform), int64 -> fp32 narrowing happens in registers (no cast kernel).
+template <typename LabelT>
+__device__ __forceinline__ void stage_rows_t(float2 *sy, const float *__restrict__ srow,
+                                             const LabelT *__restrict__ yrow, int L, int nb,
+                                             int tid, int T)
+{
+    for (int m = tid; m < L; m += T) {
+        const float sv = srow[m];
+        const float yv = (float)yrow[m];
+        if (m < nb) sy[m] = make_float2(sv, yv);
+    }
+}
+
+__device__ __forceinline__ void stage_rows(float2 *sy, const float *srow, const void *rel,
+                                           int dtype, size_t row, int L, int nb, int tid, int T)
+{
+    if (dtype == LTR_LABEL_I64)
+        stage_rows_t(sy, srow, (const int64_t *)rel + row, L, nb, tid, T);
+    else if (dtype == LTR_LABEL_F32)
+        stage_rows_t(sy, srow, (const float *)rel + row, L, nb, tid, T);
+    else
+        stage_rows_t(sy, srow, (const int32_t *)rel + row, L, nb, tid, T);
+}
+
 __device__ __forceinline__ int clamp_n(int64_t n, int L)
 {
     return n < 0 ? 0 : (n > (int64_t)L ? L : (int)n);
@@ -370,17 +395,27 @@ pairwise_loss_kernel(LossParams p)
     const int msplit = p.msplit;
     const int nb = clamp_n(p.n[b], L);
     const QueryLds q = carve_query_lds<KIND>(smem, L4, msplit);
+#if defined(LTR_DEBUG_STOP) && LTR_DEBUG_STOP == 0
+    if (p.B >= 0) return;                        // tuning: launch + dispatch floor
+#endif
 
-    // ---- stage the real documents of this query: coalesced 4 B / 8 B per lane ----
+    // ---- stage this query's (score, label) row: coalesced 4 B / 8 B per lane.  The loads do
+    // not wait for n[b] (they are issued for the whole row and only the first n[b] entries
+    // are kept), so the n, score and label fetches overlap instead of chaining latencies ----
     const size_t row = (size_t)b * L;
-    for (int m = tid; m < nb; m += T)
-        q.sy[m] = make_float2(p.scores[row + m], load_label(p.rel, p.rel_dtype, row + m));
+    stage_rows(q.sy, p.scores + row, p.rel, p.rel_dtype, row, L, nb, tid, T);
     if (KIND == LTR_NDCG1 || KIND == LTR_NDCG2)
         for (int m = tid; m < 2 * L4; m += T) q.rank_s[m] = 0;
     __syncthreads();
+#if defined(LTR_DEBUG_STOP) && LTR_DEBUG_STOP == 1
+    if (p.B >= 0) { if (tid == 0) p.loss[b] = q.sy[0].x; return; }   // tuning: + staging
+#endif
 
     float gscale;
     const float total = pairwise_core<KIND, DPT>(q, nb, L4, msplit, p.sigma, gscale);
+#if defined(LTR_DEBUG_STOP) && LTR_DEBUG_STOP == 2
+    if (p.B >= 0) { if (tid == 0) p.loss[b] = total; return; }       // tuning: + pair pass
+#endif
 
     if (tid == 0) p.loss[b] = total;
     if (p.dscores != nullptr) {

@@ -52,7 +52,7 @@ class _LinearLossFunction(torch.autograd.Function):
         r = prepare_relevance(relevance, X[:, :, 0])
         nn = prepare_n(n, B)
         loss = torch.empty(B, dtype=torch.float32, device=X.device)
-        part = torch.empty(B, F + 1, dtype=torch.float32, device=X.device)
+        part = torch.empty(F + 1, B, dtype=torch.float32, device=X.device)
         scores = torch.empty(B, L, dtype=torch.float32, device=X.device) if want_scores else None
         if B > 0:
             with torch.cuda.device(X.device):
@@ -72,7 +72,7 @@ class _LinearLossFunction(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, grad_loss, *unused):
         (part,) = ctx.saved_tensors
-        B, F1 = part.shape
+        F1, B = part.shape
         F = F1 - 1
         go = grad_loss.reshape(B).float().contiguous()
         dW = torch.empty(F, dtype=torch.float32, device=part.device)

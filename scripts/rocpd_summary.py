@@ -1,0 +1,37 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 rocpd .db (kernel trace, optional PMC counters) as text.
+
+    python scripts/rocpd_summary.py gpurun_out/prof_r01/bench_results.db > profiles/r01_kernel_stats.txt
+"""
+import sqlite3
+import sys
+
+
+def main(path):
+    con = sqlite3.connect(path)
+    cur = con.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    rows = cur.execute(
+        "select %s, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
+        "from kernels group by %s order by sum(end-start) desc" % (name_col, name_col)).fetchall()
+    total = sum(r[2] for r in rows) or 1
+    print("# kernel-trace summary of %s" % path)
+    print("%-90s %8s %12s %10s %10s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%"))
+    for name, calls, tot, avg, mn, mx in rows:
+        print("%-90s %8d %12.1f %10.2f %10.2f %10.2f %6.1f" % (
+            name[:90], calls, tot / 1e3, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * tot / total))
+    try:
+        pm = cur.execute(
+            "select k.%s, p.counter_name, count(*), avg(p.value), sum(p.value) from pmc_events p "
+            "join kernels k on k.id = p.dispatch_id group by k.%s, p.counter_name" % (name_col, name_col)).fetchall()
+    except sqlite3.Error:
+        pm = []
+    if pm:
+        print("\n# PMC counters (avg per dispatch)")
+        for name, ctr, cnt, avg, tot in pm:
+            print("%-70s %-28s n=%-6d avg=%.1f" % (name[:70], ctr, cnt, avg))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -1,0 +1,95 @@
+#!/usr/bin/env python
+"""Time kernel variants on the GPU: python scripts/tune.py build/variants/*.so [--workload c2]"""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import WORKLOADS, synth, time_events  # noqa: E402
+from pytorchltr_amd import _C  # noqa: E402
+
+KIND = {"hinge": 0, "dcg_hinge": 1, "logistic": 2, "arp1": 3, "arp2": 4, "ndcg1": 5, "ndcg2": 6}
+
+
+def load(path):
+    h = ctypes.CDLL(path)
+    for name, (restype, argtypes) in _C.SIGNATURES.items():
+        fn = getattr(h, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return h
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("libs", nargs="+")
+    ap.add_argument("--workload", default="c2")
+    ap.add_argument("--full", action="store_true")
+    ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--loss-cfgs", default="")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    B, L, F, kind = WORKLOADS[args.workload]
+    scores, rel, n, X = synth(B, L, F, 0, dev)
+    if args.full:
+        n = torch.full_like(n, L)
+    W = torch.randn(F, device=dev) * 0.1
+    bias = torch.zeros(1, device=dev)
+    loss = torch.empty(B, device=dev)
+    part = torch.empty(B * (F + 1) + 1024, device=dev)
+    ds = torch.empty(B, L, device=dev)
+    dW = torch.empty(F, device=dev)
+    db = torch.empty(1, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    k = KIND[kind]
+    ref = None
+    for path in args.libs:
+        lib = load(path)
+
+        def fused():
+            rc = lib.ltr_linear_partials_f32(k, 1.0, X.data_ptr(), W.data_ptr(), bias.data_ptr(),
+                                             rel.data_ptr(), 0, n.data_ptr(), B, L, F, loss.data_ptr(),
+                                             None, part.data_ptr(), st)
+            assert rc == 0, rc
+
+        def reduce():
+            rc = lib.ltr_linear_reduce_f32(part.data_ptr(), None, B, F, dW.data_ptr(), db.data_ptr(), st)
+            assert rc == 0, rc
+
+        def lossk():
+            rc = lib.ltr_pairwise_loss_f32(k, 1.0, scores.data_ptr(), rel.data_ptr(), 0, n.data_ptr(),
+                                           B, L, loss.data_ptr(), ds.data_ptr(), st)
+            assert rc == 0, rc
+
+        out = [os.path.basename(path)]
+        for name, fn in (("fused", fused), ("reduce", reduce), ("loss", lossk)):
+            for _ in range(10):
+                fn()
+            avg, med, mn = time_events(fn, args.iters)
+            out.append("%s avg %.2f med %.2f min %.2f us" % (name, avg, med, mn))
+        fused(); reduce()
+        torch.cuda.synchronize()
+        chk = (float(loss.double().sum()), float(dW.double().abs().sum()))
+        if ref is None:
+            ref = chk
+        out.append("chk %.6g %.6g%s" % (chk[0], chk[1], "" if abs(chk[0] - ref[0]) < 1e-3 * abs(ref[0]) + 1e-6 and abs(chk[1] - ref[1]) < 1e-3 * abs(ref[1]) + 1e-6 else "  MISMATCH"))
+        for cfg in [c for c in args.loss_cfgs.split(";") if c]:
+            o, d, m = (int(v) for v in cfg.split(","))
+
+            def lossc():
+                rc = lib.ltr_pairwise_loss_f32_cfg(k, 1.0, scores.data_ptr(), rel.data_ptr(), 0, n.data_ptr(),
+                                                   B, L, loss.data_ptr(), ds.data_ptr(), o, d, m, st)
+                assert rc == 0, rc
+            for _ in range(10):
+                lossc()
+            avg, med, mn = time_events(lossc, args.iters)
+            out.append("loss[%s] avg %.2f min %.2f" % (cfg, avg, mn))
+        print(" | ".join(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -284,7 +284,8 @@ def test_full_size_metrics_c3():
     has_rel = (y.numpy().sum(axis=1) > 0)
     assert np.allclose(ideal[has_rel], 1.0, atol=1e-6)
     curve = ev.dcg(ts, ty, tn).cpu().numpy()
-    assert np.all(np.diff(curve, axis=1) >= -1e-6)                  # cumulative
+    # cumulative (a parallel prefix sum is monotone only up to an ulp of the running value)
+    assert np.all(np.diff(curve, axis=1) >= -2e-6 * np.abs(curve[:, 1:]) - 1e-6)
     assert np.allclose(curve[:, 9], ev.dcg(ts, ty, tn, k=10).cpu().numpy(), rtol=2e-6, atol=1e-6)
     a = ev.arp(ts, ty, tn).cpu().numpy()
     assert np.allclose(a, O.arp(s.numpy(), y.numpy(), n.numpy()), rtol=2e-6, atol=1e-6)
