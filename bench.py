@@ -262,14 +262,16 @@ def main():
         W = fused.weight.detach().reshape(F).contiguous()
         bvec = fused.bias.detach().reshape(1).contiguous()
         lossv = torch.empty(B, device=dev)
-        part = torch.empty(F + 1, B, device=dev)
-        stream = torch.cuda.current_stream().cuda_stream
+        part = torch.empty(lib.ltr_linear_workspace_bytes(B, L, F) // 4, device=dev)
+        def cur_stream():
+            # resolved per call: inside hipGraph capture the current stream is the capture stream
+            return torch.cuda.current_stream().cuda_stream
 
         def launch_fused():
             _C.check(lib.ltr_linear_partials_f32(
                 getattr(_C, kind.upper()), 1.0, X.data_ptr(), W.data_ptr(), bvec.data_ptr(),
                 relevance.data_ptr(), _C.LABEL_I64, n.data_ptr(), B, L, F, lossv.data_ptr(), None,
-                part.data_ptr(), stream))
+                part.data_ptr(), cur_stream()))
 
         for _ in range(10):
             launch_fused()
@@ -318,7 +320,7 @@ def main():
         def launch_loss():
             _C.check(lib.ltr_pairwise_loss_f32(
                 getattr(_C, kind.upper()), 1.0, scores.data_ptr(), relevance.data_ptr(),
-                _C.LABEL_I64, n.data_ptr(), B, L, lossv.data_ptr(), dsc.data_ptr(), stream))
+                _C.LABEL_I64, n.data_ptr(), B, L, lossv.data_ptr(), dsc.data_ptr(), cur_stream()))
 
         for _ in range(10):
             launch_loss()

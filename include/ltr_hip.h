@@ -133,7 +133,7 @@ int ltr_batch_pairs(const void *x, int elem_bytes, int B, int L, void *out, void
  * grad_out (B) may be NULL, meaning 1/B for every query (`.mean().backward()`).
  * Rows l >= n[b] are never read (their gradient is 0) unless scores_out is requested; when
  * the (L x F) tile fits in LDS the features cross HBM exactly once.
- * `workspace` needs ltr_linear_workspace_bytes(B,L,F) bytes (per-query partials).
+ * `workspace` needs ltr_linear_workspace_bytes(B,L,F) bytes (per-query partials + scratch).
  */
 size_t ltr_linear_workspace_bytes(int B, int L, int F);
 int ltr_linear_pairwise_f32(int kind, float sigma, const float *X, const float *W,
@@ -145,7 +145,9 @@ int ltr_linear_pairwise_f32(int kind, float sigma, const float *X, const float *
 /* The same step split at the autograd boundary (forward / backward of a fused
  * Linear+loss module): partials is (F+1, B) row-major -- partials[f, b] = d loss[b] / dW_f for
  * f < F, partials[F, b] = d loss[b] / d bias -- so that the reduction over queries reads
- * contiguously; then dW_f = sum_b grad_out[b] * partials[f, b], db likewise (grad_out NULL = 1/B). */
+ * contiguously; then dW_f = sum_b grad_out[b] * partials[f, b], db likewise (grad_out NULL = 1/B).
+ * The `partials` buffer must be ltr_linear_workspace_bytes(B,L,F) bytes: the (F+1)*B matrix is
+ * followed by a small scratch tail (work-queue ticket of the persistent kernel). */
 int ltr_linear_partials_f32(int kind, float sigma, const float *X, const float *W,
                             const float *bias, const void *rel, int rel_dtype,
                             const int64_t *n, int B, int L, int F, float *loss,

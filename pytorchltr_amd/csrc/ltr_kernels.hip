@@ -64,16 +64,55 @@ __device__ __forceinline__ void stage_rows(float2 *sy, const float *srow, const 
         stage_rows_t(sy, srow, (const int32_t *)rel + row, L, nb, tid, T);
 }
 
+// Labels only (the fused scorer kernels compute the scores themselves).
+template <typename LabelT>
+__device__ __forceinline__ void stage_labels_t(float2 *sy, const LabelT *__restrict__ yrow, int L,
+                                               int nb, int tid, int T)
+{
+    for (int m = tid; m < L; m += T) {
+        const float yv = (float)yrow[m];
+        if (m < nb) sy[m].y = yv;
+    }
+}
+
+__device__ __forceinline__ void stage_labels(float2 *sy, const void *rel, int dtype, size_t row,
+                                             int L, int nb, int tid, int T)
+{
+    if (dtype == LTR_LABEL_I64) stage_labels_t(sy, (const int64_t *)rel + row, L, nb, tid, T);
+    else if (dtype == LTR_LABEL_F32) stage_labels_t(sy, (const float *)rel + row, L, nb, tid, T);
+    else stage_labels_t(sy, (const int32_t *)rel + row, L, nb, tid, T);
+}
+
 __device__ __forceinline__ int clamp_n(int64_t n, int L)
 {
     return n < 0 ? 0 : (n > (int64_t)L ? L : (int)n);
 }
 
+// Cross-lane adds on the DPP path (no LDS round trip; HIP's __shfl_* lower to ds_bpermute).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float v)
+{
+    // lanes outside ROW_MASK (or without a valid source) receive 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+
+// Sum over the 4 lanes of a quad; every lane of the quad gets the result.
+__device__ __forceinline__ float quad_sum(float v)
+{
+    v += dpp_move<0xB1, 0xF>(v);      // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E, 0xF>(v);      // quad_perm [2,3,0,1]
+    return v;
+}
+
+// Sum over the 64 lanes of the wave; every lane gets the result (DPP row ops + one readlane).
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-    return v;
+    v = quad_sum(v);
+    v += dpp_move<0x141, 0xF>(v);     // row_half_mirror: 8-lane sums
+    v += dpp_move<0x140, 0xF>(v);     // row_mirror: every lane holds its 16-lane row sum
+    v += dpp_move<0x142, 0xA>(v);     // row_bcast15 -> rows 1 and 3 add the previous row
+    v += dpp_move<0x143, 0xC>(v);     // row_bcast31 -> rows 2 and 3 add rows 0+1: lane 63 = total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // Sum over the whole workgroup; every thread gets the result.  Deterministic order.
@@ -280,9 +319,10 @@ __device__ __forceinline__ float pairwise_core(const QueryLds &q, int nb, int L4
     float2 *sy = q.sy;
 
     // slice of the streamed index this thread's wave walks
+    // (slices are whole waves, so these bounds are wave-uniform: keep them in SGPRs)
     const int mlen = (nb + msplit - 1) / msplit;
-    const int m0 = slice * mlen;
-    const int m1 = min(nb, m0 + mlen);
+    const int m0 = __builtin_amdgcn_readfirstlane(slice * mlen);
+    const int m1 = __builtin_amdgcn_readfirstlane(min(nb, m0 + mlen));
     const float c1 = sigma * kLog2e;
 
     // ---- NDCG kinds: ranks by score and by label, maxDCG, gains ----
@@ -539,8 +579,8 @@ metric_kernel(MetricParams p)
     __syncthreads();
 
     const int mlen = (nb + msplit - 1) / msplit;
-    const int m0 = slice * mlen;
-    const int m1 = min(nb, m0 + mlen);
+    const int m0 = __builtin_amdgcn_readfirstlane(slice * mlen);
+    const int m1 = __builtin_amdgcn_readfirstlane(min(nb, m0 + mlen));
     const bool with_y = (OP == METRIC_DCG) && p.normalize;
     if (with_y)
         count_ranks<DPT, true>(sy, nb, owners, o, m0, m1, msplit > 1, rank_s, rank_y);

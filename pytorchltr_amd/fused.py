@@ -52,7 +52,9 @@ class _LinearLossFunction(torch.autograd.Function):
         r = prepare_relevance(relevance, X[:, :, 0])
         nn = prepare_n(n, B)
         loss = torch.empty(B, dtype=torch.float32, device=X.device)
-        part = torch.empty(F + 1, B, dtype=torch.float32, device=X.device)
+        ws_bytes = _C.lib().ltr_linear_workspace_bytes(B, L, F)
+        ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=X.device)
+        part = ws[:(F + 1) * B].view(F + 1, B)        # (F+1, B) partials; tail = kernel scratch
         scores = torch.empty(B, L, dtype=torch.float32, device=X.device) if want_scores else None
         if B > 0:
             with torch.cuda.device(X.device):

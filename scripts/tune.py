@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--loss-cfgs", default="")
+    ap.add_argument("--trace", action="store_true", help="libs built with -DLTR_TRACE: per-phase cycle stamps")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     B, L, F, kind = WORKLOADS[args.workload]
@@ -47,13 +48,15 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     k = KIND[kind]
     ref = None
+    trbuf = torch.zeros(B * 8, dtype=torch.int64, device=dev) if args.trace else None
+    so_ptr = trbuf.data_ptr() if args.trace else None
     for path in args.libs:
         lib = load(path)
 
         def fused():
             rc = lib.ltr_linear_partials_f32(k, 1.0, X.data_ptr(), W.data_ptr(), bias.data_ptr(),
                                              rel.data_ptr(), 0, n.data_ptr(), B, L, F, loss.data_ptr(),
-                                             None, part.data_ptr(), st)
+                                             so_ptr, part.data_ptr(), st)
             assert rc == 0, rc
 
         def reduce():
@@ -77,6 +80,33 @@ def main():
         if ref is None:
             ref = chk
         out.append("chk %.6g %.6g%s" % (chk[0], chk[1], "" if abs(chk[0] - ref[0]) < 1e-3 * abs(ref[0]) + 1e-6 and abs(chk[1] - ref[1]) < 1e-3 * abs(ref[1]) + 1e-6 else "  MISMATCH"))
+        if args.trace:
+            tr = trbuf
+            for _ in range(3):
+                rc = lib.ltr_linear_partials_f32(k, 1.0, X.data_ptr(), W.data_ptr(), bias.data_ptr(),
+                                                 rel.data_ptr(), 0, n.data_ptr(), B, L, F, loss.data_ptr(),
+                                                 tr.data_ptr(), part.data_ptr(), st)
+                assert rc == 0
+            torch.cuda.synchronize()
+            t = tr.cpu().view(B, 8).double()
+            t0 = t[:, 0].min()
+            names = ["dma+labels", "gemv", "pair", "gfin", "dW", ]
+            d = t[:, 1:6] - t[:, 0:5]
+            print("  trace (cycles): kernel span %.0f | per-query mean " % (t[:, 5].max() - t0) +
+                  " ".join("%s %.0f" % (nm, d[:, i].mean()) for i, nm in enumerate(names)) +
+                  " | total/query mean %.0f max %.0f" % ((t[:, 5] - t[:, 0]).mean(), (t[:, 5] - t[:, 0]).max()))
+            nbv = t[:, 6]
+            big = nbv > 100
+            print("  queries with n>100: " + " ".join("%s %.0f" % (nm, d[big, i].mean()) for i, nm in enumerate(names)))
+            blk = t[:, 7].long()
+            per_block_end = torch.zeros(int(blk.max()) + 1).double()
+            per_block_cnt = torch.zeros(int(blk.max()) + 1)
+            for i in range(B):
+                per_block_end[blk[i]] = max(per_block_end[blk[i]], t[i, 5] - t0)
+                per_block_cnt[blk[i]] += 1
+            print("  block end cycles: min %.0f mean %.0f max %.0f | queries per block min %d max %d; first-start spread %.0f" % (
+                per_block_end.min(), per_block_end.mean(), per_block_end.max(), per_block_cnt.min(), per_block_cnt.max(),
+                (t[:, 0].sort().values[min(B, 512) - 1] - t0)))
         for cfg in [c for c in args.loss_cfgs.split(";") if c]:
             o, d, m = (int(v) for v in cfg.split(","))
 
