@@ -57,6 +57,16 @@ def synth(B, L, F, seed, device):
     return scores.to(device), relevance.to(device), n.to(device), X.to(device)
 
 
+def fused_kernel_name(L, F):
+    """Which kernel ltr_linear_partials_f32 dispatches to (mirrors choose_regtile_shape)."""
+    if F % 4 == 0 and L <= 512:
+        C = F // 4
+        R = 512 // C if C <= 512 else 0
+        if R > 0 and (L + R - 1) // R <= 9:
+            return "linear_regtile_kernel"
+    return "linear_pairwise_kernel"
+
+
 def time_events(fn, iters):
     """Per-launch duration (us) of fn() with ONE HIP event pair per launch, on the stream the
     kernels are launched on (torch's current stream).  Includes the event-record overhead
@@ -106,8 +116,13 @@ def time_wall(fn, steps, barrier):
     return time.perf_counter() - t0
 
 
+GRAPHS_OK = True     # cleared when a process group exists (see main)
+
+
 def try_graph(step, warm=3):
     """Capture `step` (forward + backward) into a hipGraph; returns replay fn or None."""
+    if not GRAPHS_OK:
+        return None
     try:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -117,7 +132,7 @@ def try_graph(step, warm=3):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             step()
         torch.cuda.synchronize()
         graph.replay()
@@ -193,11 +208,19 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("LTR_BENCH_FORCE_DIST") == "1":    # force: smoke-test RCCL at N=1
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     n_gpus = world
+    if dist is not None:
+        # ProcessGroupNCCL's watchdog thread polls HIP events; an event query while another
+        # thread is capturing aborts the process ("operation not permitted when stream is
+        # capturing").  With a process group alive, launch eagerly -- the direct C-ABI step is
+        # host-cheap (3 launches + 1 collective) and was as fast as graph replay at N=1.
+        global GRAPHS_OK
+        GRAPHS_OK = False
 
     def barrier():
         if dist is not None:
@@ -205,7 +228,6 @@ def main():
 
     from pytorchltr_amd import _C
     from pytorchltr_amd import loss as L_
-    from pytorchltr_amd.distributed import allreduce_step
     from pytorchltr_amd.fused import FusedLinearLoss
     _C.lib()                                            # fail loudly if the extension is missing
 
@@ -214,36 +236,48 @@ def main():
     if args.full_lists:
         n = torch.full_like(n, L)
     fused = FusedLinearLoss(F, kind).to(dev)
-    params = [fused.weight, fused.bias]
+    lib = _C.lib()
+    kind_id = getattr(_C, kind.upper())
+    W = fused.weight.detach().reshape(F).contiguous()
+    bvec = fused.bias.detach().reshape(1).contiguous()
+    lossv = torch.empty(B, device=dev)
+    ws_bytes = lib.ltr_linear_workspace_bytes(B, L, F)
+    part = torch.empty(ws_bytes // 4, device=dev)
+    # [dW (F) | db (1) | loss_sum | count]: the one bucket that is all-reduced when N > 1
+    flat = torch.zeros(F + 3, device=dev)
+    flat[F + 2] = float(B)
+    # uniform upstream gradient 1/(B*N): after the SUM all-reduce the bucket holds the gradient
+    # of the GLOBAL mean loss -- what `.mean().backward()` gives on the unsharded batch
+    go = torch.full((B,), 1.0 / (B * n_gpus), device=dev)
 
-    # ---- the step: fused scorer + loss forward, backward to dW/db (sum; the all-reduce
-    # bucket turns it into the global mean), all-reduce when sharded over ranks ----
+    def cur_stream():
+        # resolved per call: inside hipGraph capture the current stream is the capture stream
+        return torch.cuda.current_stream().cuda_stream
+
+    # ---- the step: fused scorer + loss forward, backward to dW/db, through the C ABI ----
     def fwd_bwd():
-        for p in params:
-            p.grad = None
-        per_query = fused(X, relevance, n)
-        total = per_query.sum()
-        total.backward()
-        return total
+        st = cur_stream()
+        _C.check(lib.ltr_linear_partials_f32(
+            kind_id, 1.0, X.data_ptr(), W.data_ptr(), bvec.data_ptr(), relevance.data_ptr(),
+            _C.LABEL_I64, n.data_ptr(), B, L, F, lossv.data_ptr(), None, part.data_ptr(), st))
+        _C.check(lib.ltr_linear_reduce_f32(part.data_ptr(), go.data_ptr(), B, F, flat.data_ptr(),
+                                           flat.data_ptr() + 4 * F, st))
+        torch.sum(lossv, dim=0, keepdim=True, out=flat[F + 1:F + 2])
 
-    state = {}
-
-    def step_eager():
-        state["loss_sum"] = fwd_bwd().detach()
-        if dist is not None:
-            state["mean_loss"], _ = allreduce_step([p.grad for p in params], state["loss_sum"], B)
-
-    replay = None if args.no_graph else try_graph(lambda: state.__setitem__("loss_sum", fwd_bwd().detach()))
-
-    def step_graph():
-        replay()
-        if dist is not None:
-            state["mean_loss"], _ = allreduce_step([p.grad for p in params], state["loss_sum"], B)
+    def fwd_bwd_allreduce():
+        fwd_bwd()
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
 
     results = {}
-    for name, fn in (("eager", step_eager), ("hipgraph", step_graph if replay else None)):
-        if fn is None:
-            continue
+    modes = {}
+    if dist is None:
+        modes["eager"] = fwd_bwd
+        replay = None if args.no_graph else try_graph(fwd_bwd)
+        if replay is not None:
+            modes["hipgraph"] = replay
+    else:
+        modes["eager"] = fwd_bwd_allreduce
+    for name, fn in modes.items():
         for _ in range(args.warmup):
             fn()
         elapsed = time_wall(fn, args.steps, barrier)
@@ -251,25 +285,16 @@ def main():
         if dist is not None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         results[name] = float(t.item())
-    mode = "hipgraph" if "hipgraph" in results else "eager"
+    mode = min(results, key=results.get)
     elapsed = results[mode]
     value = n_gpus * B * args.steps / elapsed
 
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel: fused scorer+loss, timed live with HIP events ----
-        lib = _C.lib()
-        W = fused.weight.detach().reshape(F).contiguous()
-        bvec = fused.bias.detach().reshape(1).contiguous()
-        lossv = torch.empty(B, device=dev)
-        part = torch.empty(lib.ltr_linear_workspace_bytes(B, L, F) // 4, device=dev)
-        def cur_stream():
-            # resolved per call: inside hipGraph capture the current stream is the capture stream
-            return torch.cuda.current_stream().cuda_stream
-
         def launch_fused():
             _C.check(lib.ltr_linear_partials_f32(
-                getattr(_C, kind.upper()), 1.0, X.data_ptr(), W.data_ptr(), bvec.data_ptr(),
+                kind_id, 1.0, X.data_ptr(), W.data_ptr(), bvec.data_ptr(),
                 relevance.data_ptr(), _C.LABEL_I64, n.data_ptr(), B, L, F, lossv.data_ptr(), None,
                 part.data_ptr(), cur_stream()))
 
@@ -288,7 +313,7 @@ def main():
                 traffic = json.load(fh).get("hbm_bytes_per_launch")
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "kernel": "linear_pairwise_kernel<%s>" % kind,
+                    "kernel": "%s<%s> (via ltr_linear_partials_f32)" % (fused_kernel_name(L, F), kind),
                     "kernel_us_avg": k_avg,
                     "timing": "HIP events around %s back-to-back launches" % ("hipGraph-replayed" if k_graphed else "eager"),
                     "kernel_us_single_launch_event_pair": {"avg": k_evt_avg, "median": k_evt_med, "min": k_evt_min},
@@ -307,14 +332,36 @@ def main():
             loss_fn(sc, relevance, n).mean().backward()
 
         extra = {"step_seconds": results}
-        for _ in range(args.warmup):
-            loss_step()
-        t_loss = time_wall(loss_step, args.steps, lambda: None)
-        extra["loss_only_eager_queries_per_s"] = B * args.steps / t_loss
-        lreplay = None if args.no_graph else try_graph(loss_step)
-        if lreplay is not None:
-            t_lg = time_wall(lreplay, args.steps, lambda: None)
-            extra["loss_only_hipgraph_queries_per_s"] = B * args.steps / t_lg
+
+        def measure(stepfn):
+            for _ in range(args.warmup):
+                stepfn()
+            res = {"eager_queries_per_s": B * args.steps / time_wall(stepfn, args.steps, lambda: None)}
+            rp = None if args.no_graph else try_graph(stepfn)
+            if rp is not None:
+                res["hipgraph_queries_per_s"] = B * args.steps / time_wall(rp, args.steps, lambda: None)
+            return res
+
+        # (a) the fused op as an autograd module: FusedLinearLoss(...)(xs, ys, n).mean().backward()
+        params = [fused.weight, fused.bias]
+
+        def module_step():
+            for p_ in params:
+                p_.grad = None
+            fused(X, relevance, n).mean().backward()
+        extra["fused_module_autograd"] = measure(module_step)
+
+        # (b) the reference's own user code, unfused drop-in: torch Linear + our loss module
+        lin = torch.nn.Linear(F, 1).to(dev)
+
+        def dropin_step():
+            lin.weight.grad = None
+            lin.bias.grad = None
+            loss_fn(lin(X), relevance, n).mean().backward()
+        extra["dropin_linear_plus_loss_module"] = measure(dropin_step)
+
+        # (c) loss only (the literal "loss fwd+bwd" on precomputed scores)
+        extra["loss_only_module"] = measure(loss_step)
         dsc = torch.empty(B, L, device=dev)
 
         def launch_loss():
@@ -332,7 +379,6 @@ def main():
                                 "algorithmic_bytes_per_launch": loss_bytes,
                                 "achieved_GBs": loss_bytes / (l_avg * 1e-6) / 1e9,
                                 "frac_of_hbm_peak": loss_bytes / (l_avg * 1e-6) / 1e9 / HBM_PEAK_GBS}
-        extra["eager_queries_per_s"] = n_gpus * B * args.steps / results["eager"]
 
         cpu = None
         if n_gpus == 1 and not args.no_cpu_baseline:

@@ -130,6 +130,22 @@ __device__ __forceinline__ float block_sum(float v, float *red)
     return t;
 }
 
+// Two sums in one pass (same barriers): used for (loss, sum of gradients).
+__device__ __forceinline__ void block_sum2(float &a, float &b, float *red)
+{
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int nw = blockDim.x >> 6;
+    if (nw == 1) return;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = a; red[2 * (threadIdx.x >> 6) + 1] = b; }
+    __syncthreads();
+    float ta = 0.f, tb = 0.f;
+    for (int i = 0; i < nw; ++i) { ta += red[2 * i]; tb += red[2 * i + 1]; }
+    a = ta;
+    b = tb;
+}
+
 // log2(1 + e) for e in [0, 1]; two-term series below 2^-10 where 1+e would round e away.
 __device__ __forceinline__ float log2_1p(float e)
 {
@@ -306,10 +322,11 @@ __device__ __forceinline__ QueryLds carve_query_lds(unsigned char *base, int L4,
 // Precondition: q.sy[0..nb) = (score, label) is staged and visible (barrier passed); for the
 // NDCG kinds q.rank_s[0..2*L4) is zeroed.  Postcondition (after the trailing barrier):
 // q.gpart[slice*L4 + k] holds the slice partials of d(pair sum)/d s_k in units of `gscale`;
-// returns the final per-query loss (modifier applied) to every thread.
+// returns the final per-query loss (modifier applied) to every thread and, in `gsum`, the sum
+// over documents of d loss / d s_k (= d loss / d bias of a linear scorer; ~0 by construction).
 template <int KIND, int DPT>
 __device__ __forceinline__ float pairwise_core(const QueryLds &q, int nb, int L4, int msplit,
-                                               float sigma, float &gscale)
+                                               float sigma, float &gscale, float &gsum)
 {
     const int tid = threadIdx.x;
     const int T = blockDim.x;
@@ -353,7 +370,7 @@ __device__ __forceinline__ float pairwise_core(const QueryLds &q, int nb, int L4
     }
 
     // ---- pair pass ----
-    float lacc = 0.f;
+    float lacc = 0.f, gacc = 0.f;
     for (int base = 0; base < nb; base += owners * DPT) {
         const int wave_first = base + (o & ~63);
         if (wave_first >= nb) continue;                          // wave-uniform
@@ -403,11 +420,12 @@ __device__ __forceinline__ float pairwise_core(const QueryLds &q, int nb, int L4
         }
 #pragma unroll
         for (int c = 0; c < DPT; ++c)
-            if (kk[c] < nb) q.gpart[(size_t)slice * L4 + kk[c]] = gk[c];
+            if (kk[c] < nb) { q.gpart[(size_t)slice * L4 + kk[c]] = gk[c]; gacc += gk[c]; }
     }
 
-    // ---- per-query reduction and loss modifier ----
-    float total = block_sum(lacc, q.red);     // its barriers publish gpart when there are >= 2 waves
+    // ---- per-query reduction (loss and gradient sum in one pass) and loss modifier ----
+    float total = lacc;
+    block_sum2(total, gacc, q.red);           // its barriers publish gpart when there are >= 2 waves
     if (T == kWave) __syncthreads();
     gscale = 1.0f;
     if (KIND == LTR_DCG_HINGE) {
@@ -419,6 +437,7 @@ __device__ __forceinline__ float pairwise_core(const QueryLds &q, int nb, int L4
     } else if (KIND != LTR_HINGE) {
         gscale = sigma / kLn2;
     }
+    gsum = gacc * gscale;
     return total;
 }
 
@@ -451,8 +470,8 @@ pairwise_loss_kernel(LossParams p)
     if (p.B >= 0) { if (tid == 0) p.loss[b] = q.sy[0].x; return; }   // tuning: + staging
 #endif
 
-    float gscale;
-    const float total = pairwise_core<KIND, DPT>(q, nb, L4, msplit, p.sigma, gscale);
+    float gscale, gsum;
+    const float total = pairwise_core<KIND, DPT>(q, nb, L4, msplit, p.sigma, gscale, gsum);
 #if defined(LTR_DEBUG_STOP) && LTR_DEBUG_STOP == 2
     if (p.B >= 0) { if (tid == 0) p.loss[b] = total; return; }       // tuning: + pair pass
 #endif

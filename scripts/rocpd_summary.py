@@ -23,14 +23,17 @@ def main(path):
             name[:90], calls, tot / 1e3, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * tot / total))
     try:
         pm = cur.execute(
-            "select k.%s, p.counter_name, count(*), avg(p.value), sum(p.value) from pmc_events p "
-            "join kernels k on k.id = p.dispatch_id group by k.%s, p.counter_name" % (name_col, name_col)).fetchall()
+            "select kernel_name, counter_name, count(*), avg(value), min(value), max(value) "
+            "from counters_collection group by kernel_name, counter_name "
+            "order by kernel_name, counter_name").fetchall()
     except sqlite3.Error:
         pm = []
     if pm:
-        print("\n# PMC counters (avg per dispatch)")
-        for name, ctr, cnt, avg, tot in pm:
-            print("%-70s %-28s n=%-6d avg=%.1f" % (name[:70], ctr, cnt, avg))
+        print("\n# PMC counters per dispatch (avg / min / max over dispatches)")
+        for name, ctr, cnt, avg, mn, mx in pm:
+            if name.startswith("void at::") or name.startswith("__amd"):
+                continue
+            print("%-70s %-22s n=%-5d avg=%-14.1f min=%-14.1f max=%.1f" % (name[:70], ctr, cnt, avg, mn, mx))
 
 
 if __name__ == "__main__":
