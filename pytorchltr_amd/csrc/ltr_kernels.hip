@@ -324,7 +324,7 @@ __device__ __forceinline__ QueryLds carve_query_lds(unsigned char *base, int L4,
 // q.gpart[slice*L4 + k] holds the slice partials of d(pair sum)/d s_k in units of `gscale`;
 // returns the final per-query loss (modifier applied) to every thread and, in `gsum`, the sum
 // over documents of d loss / d s_k (= d loss / d bias of a linear scorer; ~0 by construction).
-template <int KIND, int DPT>
+template <int KIND, int DPT, bool PIPE = true>
 __device__ __forceinline__ float pairwise_core(const QueryLds &q, int nb, int L4, int msplit,
                                                float sigma, float &gscale, float &gsum)
 {
@@ -337,8 +337,8 @@ __device__ __forceinline__ float pairwise_core(const QueryLds &q, int nb, int L4
 
     // slice of the streamed index this thread's wave walks
     // (slices are whole waves, so these bounds are wave-uniform: keep them in SGPRs)
-    const int mlen = (nb + msplit - 1) / msplit;
-    const int m0 = __builtin_amdgcn_readfirstlane(slice * mlen);
+    const int mlen = ((nb + msplit - 1) / msplit + 1) & ~1;        // even: slices start 16-B aligned
+    const int m0 = __builtin_amdgcn_readfirstlane(min(nb, slice * mlen));
     const int m1 = __builtin_amdgcn_readfirstlane(min(nb, m0 + mlen));
     const float c1 = sigma * kLog2e;
 
@@ -393,29 +393,62 @@ __device__ __forceinline__ float pairwise_core(const QueryLds &q, int nb, int L4
                 sk[c] = v.x; yk[c] = v.y;
             }
         }
-#pragma unroll 2
-        for (int m = m0; m < m1; ++m) {
+        // One streamed document against the DPT owned ones.
+        auto visit = [&](float sm, float ym, float Gm, float rm) {
+#pragma unroll
+            for (int c = 0; c < DPT; ++c) {
+                if (KIND == LTR_NDCG2) {
+                    const int d = (int)fabsf(rk[c] - rm);
+                    const float W = q.delta[d] * fabsf(Gk[c] - Gm);
+                    pair_oriented(sk[c], yk[c], sm, ym, W, c1, gk[c], lacc);
+                } else if (KIND == LTR_HINGE || KIND == LTR_DCG_HINGE) {
+                    pair_hinge(sk[c], yk[c], sm, ym, gk[c], lacc);
+                } else if (KIND == LTR_LOGISTIC) {
+                    pair_oriented(sk[c], yk[c], sm, ym, 1.0f, c1, gk[c], lacc);
+                } else if (KIND == LTR_ARP2) {
+                    pair_oriented(sk[c], yk[c], sm, ym, fabsf(yk[c] - ym), c1, gk[c], lacc);
+                } else {
+                    pair_rowweight(sk[c], yk[c], sm, ym, c1, gk[c], lacc);
+                }
+            }
+        };
+        // Streamed documents come from LDS in 64-byte chunks (4 x ds_read_b128, wave-uniform
+        // address = broadcast), software-pipelined one chunk ahead so the LDS latency hides under
+        // the pair arithmetic instead of stalling every iteration.
+        constexpr int MU = (KIND == LTR_NDCG2) ? 4 : 8;                  // documents per chunk
+        const float4 *src = (KIND == LTR_NDCG2) ? q.q4 : reinterpret_cast<const float4 *>(sy);
+        constexpr int VPD = (KIND == LTR_NDCG2) ? 1 : 2;                 // documents per float4
+        // PIPE = false (register-tight callers): plain loop, no prefetch registers
+        const int mfull = PIPE ? m0 + ((m1 - m0) / MU) * MU : m0;        // m0 is even (see mlen)
+        if (mfull > m0) {
+            float4 cur[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cur[j] = src[m0 / VPD + j];
+            for (int m = m0; m < mfull; m += MU) {
+                const int mn = (m + MU < mfull) ? (m + MU) : m;          // last chunk: harmless re-read
+                float4 nxt[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) nxt[j] = src[mn / VPD + j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (KIND == LTR_NDCG2) {
+                        visit(cur[j].x, cur[j].y, cur[j].z, cur[j].w);
+                    } else {
+                        visit(cur[j].x, cur[j].y, 0.f, 0.f);
+                        visit(cur[j].z, cur[j].w, 0.f, 0.f);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+            }
+        }
+        for (int m = mfull; m < m1; ++m) {                               // remainder (< MU documents)
             if (KIND == LTR_NDCG2) {
                 const float4 v = q.q4[m];
-#pragma unroll
-                for (int c = 0; c < DPT; ++c) {
-                    const int d = (int)fabsf(rk[c] - v.w);
-                    const float W = q.delta[d] * fabsf(Gk[c] - v.z);
-                    pair_oriented(sk[c], yk[c], v.x, v.y, W, c1, gk[c], lacc);
-                }
+                visit(v.x, v.y, v.z, v.w);
             } else {
                 const float2 v = sy[m];
-#pragma unroll
-                for (int c = 0; c < DPT; ++c) {
-                    if (KIND == LTR_HINGE || KIND == LTR_DCG_HINGE)
-                        pair_hinge(sk[c], yk[c], v.x, v.y, gk[c], lacc);
-                    else if (KIND == LTR_LOGISTIC)
-                        pair_oriented(sk[c], yk[c], v.x, v.y, 1.0f, c1, gk[c], lacc);
-                    else if (KIND == LTR_ARP2)
-                        pair_oriented(sk[c], yk[c], v.x, v.y, fabsf(yk[c] - v.y), c1, gk[c], lacc);
-                    else
-                        pair_rowweight(sk[c], yk[c], v.x, v.y, c1, gk[c], lacc);
-                }
+                visit(v.x, v.y, 0.f, 0.f);
             }
         }
 #pragma unroll

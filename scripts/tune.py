@@ -9,7 +9,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import WORKLOADS, synth, time_events  # noqa: E402
+from bench import WORKLOADS, synth, time_events, time_launches  # noqa: E402
 from pytorchltr_amd import _C  # noqa: E402
 
 KIND = {"hinge": 0, "dcg_hinge": 1, "logistic": 2, "arp1": 3, "arp2": 4, "ndcg1": 5, "ndcg2": 6}
@@ -53,19 +53,22 @@ def main():
     for path in args.libs:
         lib = load(path)
 
+        def cs():
+            return torch.cuda.current_stream().cuda_stream
+
         def fused():
             rc = lib.ltr_linear_partials_f32(k, 1.0, X.data_ptr(), W.data_ptr(), bias.data_ptr(),
                                              rel.data_ptr(), 0, n.data_ptr(), B, L, F, loss.data_ptr(),
-                                             so_ptr, part.data_ptr(), st)
+                                             so_ptr, part.data_ptr(), cs())
             assert rc == 0, rc
 
         def reduce():
-            rc = lib.ltr_linear_reduce_f32(part.data_ptr(), None, B, F, dW.data_ptr(), db.data_ptr(), st)
+            rc = lib.ltr_linear_reduce_f32(part.data_ptr(), None, B, F, dW.data_ptr(), db.data_ptr(), cs())
             assert rc == 0, rc
 
         def lossk():
             rc = lib.ltr_pairwise_loss_f32(k, 1.0, scores.data_ptr(), rel.data_ptr(), 0, n.data_ptr(),
-                                           B, L, loss.data_ptr(), ds.data_ptr(), st)
+                                           B, L, loss.data_ptr(), ds.data_ptr(), cs())
             assert rc == 0, rc
 
         out = [os.path.basename(path)]
@@ -73,7 +76,8 @@ def main():
             for _ in range(10):
                 fn()
             avg, med, mn = time_events(fn, args.iters)
-            out.append("%s avg %.2f med %.2f min %.2f us" % (name, avg, med, mn))
+            bat, _ = time_launches(fn, per_graph=20, replays=10)
+            out.append("%s %.2f us (evt-pair %.2f)" % (name, bat, avg))
         fused(); reduce()
         torch.cuda.synchronize()
         chk = (float(loss.double().sum()), float(dW.double().abs().sum()))
@@ -112,12 +116,12 @@ def main():
 
             def lossc():
                 rc = lib.ltr_pairwise_loss_f32_cfg(k, 1.0, scores.data_ptr(), rel.data_ptr(), 0, n.data_ptr(),
-                                                   B, L, loss.data_ptr(), ds.data_ptr(), o, d, m, st)
+                                                   B, L, loss.data_ptr(), ds.data_ptr(), o, d, m, cs())
                 assert rc == 0, rc
             for _ in range(10):
                 lossc()
-            avg, med, mn = time_events(lossc, args.iters)
-            out.append("loss[%s] avg %.2f min %.2f" % (cfg, avg, mn))
+            bat, _ = time_launches(lossc, per_graph=20, replays=10)
+            out.append("loss[%s] %.2f" % (cfg, bat))
         print(" | ".join(out), flush=True)
 
 
