@@ -120,7 +120,9 @@ def test_module_autograd_path_mean_backward(kind):
 
 @pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("cfg", [(64, 1, 1), (64, 2, 1), (64, 4, 1), (128, 1, 2), (128, 2, 4),
-                                 (256, 4, 4), (256, 1, 1), (512, 2, 2), (1024, 1, 1)])
+                                 (256, 4, 4), (256, 1, 1), (512, 2, 2), (1024, 1, 1),
+                                 # dpt == 0: symmetric pair pass, owners*msplit threads
+                                 (64, 0, 1), (64, 0, 2), (128, 0, 2), (256, 0, 2), (256, 0, 4)])
 def test_launch_shapes_agree(kind, cfg):
     """Every (owners, documents-per-thread, split) launch shape computes the same thing."""
     s, y, n = synth(12, 200, 9)
