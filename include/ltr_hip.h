@@ -83,7 +83,7 @@ int ltr_pairwise_loss_f32(int kind, float sigma, const float *scores, const void
 /* Same, with an explicit launch shape (tuning/tests): `owners` threads each own `dpt`
  * documents per chunk, the pair loop is split `msplit` ways; block = owners*msplit
  * threads.  owners % 64 == 0, dpt in {1,2,4}, owners*msplit <= 1024.  dpt == 0 selects the
- * symmetric pair pass (every unordered pair evaluated once; L <= 256): owners*msplit threads. */
+ * symmetric pair pass (every unordered pair evaluated once; L <= 1024): owners*msplit threads. */
 int ltr_pairwise_loss_f32_cfg(int kind, float sigma, const float *scores, const void *rel,
                               int rel_dtype, const int64_t *n, int B, int L, float *loss,
                               float *dscores, int owners, int dpt, int msplit, void *stream);

@@ -25,6 +25,7 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kMaxListLen = 4096;
+constexpr int kSymMaxLen = 1024;   // longest list the symmetric pair pass takes (LDS: one slice per wave)
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
@@ -485,7 +486,7 @@ __device__ __forceinline__ float pairwise_core(const QueryLds &q, int nb, int L4
 }
 
 // ---------------------------------------------------------------------------------
-// Symmetric pair pass (list_len <= 256): every UNORDERED pair is evaluated once.
+// Symmetric pair pass (list_len <= kSymMaxLen): every UNORDERED pair is evaluated once.
 // Documents are cut into 64-wide tiles; a job is an unordered tile pair (a, b).  A wave keeps
 // the "home" tile a in registers (lane i = document 64a+i) and a "visitor" tile b that ROTATES
 // through the lanes: at step j lane i holds visitor 64b + ((i+j) & 63) -- its score, label and
@@ -985,16 +986,18 @@ LaunchShape choose_shape(int B, int L)
     return s;
 }
 
-// Loss kernels: lists up to 256 take the symmetric pair pass (dpt == 0; measured on MI355X:
-// C2 hinge 7.7 -> 6.5 us, NDCG2 20.3 -> 16.4 us); 4 waves per query for L <= 128, 8 above.
+// Loss kernels: lists up to kSymMaxLen take the symmetric pair pass (dpt == 0; measured on MI355X:
+// C2 hinge 7.7 -> 6.5 us, NDCG2 20.3 -> 16.4 us, C5 35 -> 26 us, C4 62 -> 56 us);
+// 4 waves per query for L <= 128, 8 up to 256, 16 above.
 LaunchShape choose_loss_shape(int B, int L)
 {
 #ifndef LTR_NO_SYM
-    if (L <= 256) {
+    if (L <= kSymMaxLen) {
         LaunchShape s;
         s.dpt = 0;
         s.owners = 64;
-        s.msplit = (L <= 128) ? 4 : 8;
+        s.msplit = (L <= 128) ? 4 : (L <= 256 ? 8 : 16);   // waves per query
+        (void)B;
         return s;
     }
 #endif
@@ -1105,7 +1108,7 @@ int ltr_pairwise_loss_f32_cfg(int kind, float sigma, const float *scores, const 
     if (B == 0) return LTR_OK;
     if (!scores || !rel || !n || !loss) return LTR_ERR_NULL;
     if (owners <= 0 || owners % 64 != 0 || msplit <= 0 || owners * msplit > 1024 ||
-        (dpt != 0 && dpt != 1 && dpt != 2 && dpt != 4) || (dpt == 0 && L > 256))
+        (dpt != 0 && dpt != 1 && dpt != 2 && dpt != 4) || (dpt == 0 && L > kSymMaxLen))
         return LTR_ERR_CONFIG;
     {
         const LaunchShape chk{owners, dpt, msplit};
