@@ -260,9 +260,9 @@ def main():
         _C.check(lib.ltr_linear_partials_f32(
             kind_id, 1.0, X.data_ptr(), W.data_ptr(), bvec.data_ptr(), relevance.data_ptr(),
             _C.LABEL_I64, n.data_ptr(), B, L, F, lossv.data_ptr(), None, part.data_ptr(), st))
-        _C.check(lib.ltr_linear_reduce_f32(part.data_ptr(), go.data_ptr(), B, F, flat.data_ptr(),
-                                           flat.data_ptr() + 4 * F, st))
-        torch.sum(lossv, dim=0, keepdim=True, out=flat[F + 1:F + 2])
+        _C.check(lib.ltr_linear_reduce_loss_f32(part.data_ptr(), go.data_ptr(), lossv.data_ptr(), B, F,
+                                                flat.data_ptr(), flat.data_ptr() + 4 * F,
+                                                flat.data_ptr() + 4 * (F + 1), st))
 
     def fwd_bwd_allreduce():
         fwd_bwd()

@@ -155,6 +155,10 @@ int ltr_linear_partials_f32(int kind, float sigma, const float *X, const float *
                             float *scores_out, float *partials /* (F+1, B) */, void *stream);
 int ltr_linear_reduce_f32(const float *partials, const float *grad_out, int B, int F, float *dW,
                           float *db, void *stream);
+/* Same reduction, additionally writing loss_sum[0] = sum_b loss[b] (the scalar a training loop
+ * logs / all-reduces) in the same launch.  loss_sum may be NULL. */
+int ltr_linear_reduce_loss_f32(const float *partials, const float *grad_out, const float *loss,
+                               int B, int F, float *dW, float *db, float *loss_sum, void *stream);
 
 #ifdef __cplusplus
 }

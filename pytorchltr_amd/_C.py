@@ -37,6 +37,7 @@ SIGNATURES = {
     "ltr_linear_partials_f32": (_i, [_i, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i,
                                      _vp, _vp, _vp, _vp]),
     "ltr_linear_reduce_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "ltr_linear_reduce_loss_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None
@@ -74,8 +75,46 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+try:                                    # raw stream handle without building a Stream object
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:                  # pragma: no cover - older/newer torch
+    _raw_stream = None
+
+
 def stream_of(t):
+    """hipStream_t (as int) of torch's current stream on t's device."""
+    if _raw_stream is not None:
+        return _raw_stream(t.device.index if t.device.index is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL = _NullCtx()
+
+
+def device_ctx(t):
+    """Context that makes t's device current for the launch; free when it already is."""
+    idx = t.device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NULL
+    return torch.cuda.device(idx)
+
+
+_max_len = None
+
+
+def max_list_len():
+    global _max_len
+    if _max_len is None:
+        _max_len = int(lib().ltr_max_list_len())
+    return _max_len
 
 
 def require_device(t, what):

@@ -18,7 +18,7 @@ class PairwiseLossFunction(torch.autograd.Function):
         loss = torch.empty(B, dtype=torch.float32, device=s.device)
         ds = torch.empty(B, L, dtype=torch.float32, device=s.device) if need_grad else None
         if B > 0:
-            with torch.cuda.device(s.device):
+            with _C.device_ctx(s):
                 _C.check(_C.lib().ltr_pairwise_loss_f32(
                     kind, float(sigma), _C.ptr(s), _C.ptr(r), _C.label_dtype(r), _C.ptr(nn),
                     B, L, _C.ptr(loss), _C.ptr(ds), _C.stream_of(s)))
@@ -36,7 +36,7 @@ class PairwiseLossFunction(torch.autograd.Function):
         go = grad_out.reshape(B).float().contiguous()
         out = torch.empty_like(ds)
         if B > 0:
-            with torch.cuda.device(ds.device):
+            with _C.device_ctx(ds):
                 _C.check(_C.lib().ltr_scale_rows_f32(
                     _C.ptr(ds), _C.ptr(go), B, L, _C.ptr(out), _C.stream_of(ds)))
         out = out.reshape(ctx.in_shape)
@@ -57,7 +57,7 @@ def pairwise_loss_and_grad(scores, relevance, n, kind, sigma=1.0, cfg=None):
     loss = torch.empty(B, dtype=torch.float32, device=s.device)
     ds = torch.empty(B, L, dtype=torch.float32, device=s.device)
     if B > 0:
-        with torch.cuda.device(s.device):
+        with _C.device_ctx(s):
             if cfg is None:
                 rc = _C.lib().ltr_pairwise_loss_f32(
                     kind, float(sigma), _C.ptr(s), _C.ptr(r), _C.label_dtype(r), _C.ptr(nn),

@@ -56,7 +56,7 @@ def prepare(scores, relevance, n):
     nn = prepare_n(n, s.shape[0])
     if not (s.device == r.device == nn.device):
         raise RuntimeError("scores, relevance and n must be on the same device")
-    max_l = _C.lib().ltr_max_list_len()
+    max_l = _C.max_list_len()
     if s.shape[1] > max_l:
         raise ValueError("list_size %d exceeds the supported maximum %d" % (s.shape[1], max_l))
     if s.shape[1] == 0:

@@ -21,7 +21,7 @@ def arp(scores: _torch.FloatTensor, relevance: _torch.LongTensor,
     B, L = s.shape
     out = _torch.empty(B, dtype=_torch.float32, device=s.device)
     if B > 0:
-        with _torch.cuda.device(s.device):
+        with _C.device_ctx(s):
             _C.check(_C.lib().ltr_arp_f32(_C.ptr(s), _C.ptr(r), _C.label_dtype(r), _C.ptr(nn),
                                           B, L, _C.ptr(out), _C.stream_of(s)))
     return out

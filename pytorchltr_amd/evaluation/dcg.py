@@ -29,7 +29,7 @@ def _run(scores, relevance, n, k, exp, normalize):
     kk = _cutoff(k, L)
     out = _torch.empty((B,) if kk > 0 else (B, L), dtype=_torch.float32, device=s.device)
     if B > 0:
-        with _torch.cuda.device(s.device):
+        with _C.device_ctx(s):
             _C.check(_C.lib().ltr_dcg_f32(_C.ptr(s), _C.ptr(r), _C.label_dtype(r), _C.ptr(nn),
                                           B, L, kk, int(bool(exp)), int(normalize),
                                           _C.ptr(out), _C.stream_of(s)))

@@ -57,7 +57,7 @@ class _LinearLossFunction(torch.autograd.Function):
         part = ws[:(F + 1) * B].view(F + 1, B)        # (F+1, B) partials; tail = kernel scratch
         scores = torch.empty(B, L, dtype=torch.float32, device=X.device) if want_scores else None
         if B > 0:
-            with torch.cuda.device(X.device):
+            with _C.device_ctx(X):
                 _C.check(_C.lib().ltr_linear_partials_f32(
                     kind, float(sigma), _C.ptr(X), _C.ptr(W), _C.ptr(bvec), _C.ptr(r),
                     _C.label_dtype(r), _C.ptr(nn), B, L, F, _C.ptr(loss), _C.ptr(scores),
@@ -79,7 +79,7 @@ class _LinearLossFunction(torch.autograd.Function):
         go = grad_loss.reshape(B).float().contiguous()
         dW = torch.empty(F, dtype=torch.float32, device=part.device)
         db = torch.empty(1, dtype=torch.float32, device=part.device)
-        with torch.cuda.device(part.device):
+        with _C.device_ctx(part):
             _C.check(_C.lib().ltr_linear_reduce_f32(_C.ptr(part), _C.ptr(go), B, F, _C.ptr(dW),
                                                     _C.ptr(db), _C.stream_of(part)))
         return (None, dW.reshape(ctx.w_shape), db if ctx.has_bias else None,
@@ -113,11 +113,12 @@ class FusedLinearLoss(torch.nn.Module):
 
 
 def linear_loss_step(xs, weight, bias, relevance, n, loss="hinge", grad_out=None,
-                     return_scores=False):
-    """One fused fwd+bwd step without autograd: returns (loss[B], dW[F], db[1][, scores]).
+                     return_scores=False, return_loss_sum=False):
+    """One fused fwd+bwd step without autograd: returns (loss[B], dW[F], db[1][, scores][, loss_sum]).
 
     dW/db are the gradients of ``sum_b grad_out[b] * loss[b]``; grad_out=None means the
-    ``.mean()`` of the reference's training loop (1/B each)."""
+    ``.mean()`` of the reference's training loop (1/B each).  Two launches: the fused
+    scorer+loss kernel and the cross-query reduction (which also totals the loss)."""
     kind, sigma = _resolve_loss(loss)
     X = _prepare_features(xs)
     B, L, F = X.shape
@@ -128,15 +129,21 @@ def linear_loss_step(xs, weight, bias, relevance, n, loss="hinge", grad_out=None
     lossv = torch.empty(B, dtype=torch.float32, device=X.device)
     dW = torch.empty(F, dtype=torch.float32, device=X.device)
     db = torch.empty(1, dtype=torch.float32, device=X.device)
+    lsum = torch.zeros(1, dtype=torch.float32, device=X.device) if return_loss_sum else None
     scores = torch.empty(B, L, dtype=torch.float32, device=X.device) if return_scores else None
     ws_bytes = _C.lib().ltr_linear_workspace_bytes(B, L, F)
     ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=X.device)
     go = None if grad_out is None else grad_out.reshape(B).float().contiguous()
-    with torch.cuda.device(X.device):
-        _C.check(_C.lib().ltr_linear_pairwise_f32(
+    with _C.device_ctx(X):
+        st = _C.stream_of(X)
+        _C.check(_C.lib().ltr_linear_partials_f32(
             kind, float(sigma), _C.ptr(X), _C.ptr(W), _C.ptr(bvec), _C.ptr(r), _C.label_dtype(r),
-            _C.ptr(nn), _C.ptr(go), B, L, F, _C.ptr(lossv), _C.ptr(scores), _C.ptr(dW), _C.ptr(db),
-            _C.ptr(ws), ws_bytes, _C.stream_of(X)))
+            _C.ptr(nn), B, L, F, _C.ptr(lossv), _C.ptr(scores), _C.ptr(ws), st))
+        _C.check(_C.lib().ltr_linear_reduce_loss_f32(
+            _C.ptr(ws), _C.ptr(go), _C.ptr(lossv), B, F, _C.ptr(dW), _C.ptr(db), _C.ptr(lsum), st))
+    out = (lossv, dW, db)
     if return_scores:
-        return lossv, dW, db, scores
-    return lossv, dW, db
+        out = out + (scores,)
+    if return_loss_sum:
+        out = out + (lsum,)
+    return out

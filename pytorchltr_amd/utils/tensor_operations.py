@@ -31,7 +31,7 @@ def mask_padded_values(xs: _torch.FloatTensor, n: _torch.LongTensor,
         src = _prepare_scores(xs)
         out = _torch.empty_like(src)
     if B > 0 and L > 0:
-        with _torch.cuda.device(src.device):
+        with _C.device_ctx(src):
             _C.check(_C.lib().ltr_mask_padded_values_f32(
                 _C.ptr(src), _C.ptr(nn), B, L, float(mask_value), _C.ptr(out),
                 _C.stream_of(src)))
@@ -45,7 +45,7 @@ def _rank(scores2d, nn):
     B, L = scores2d.shape
     ranking = _torch.empty(B, L, dtype=_torch.int64, device=scores2d.device)
     if B > 0:
-        with _torch.cuda.device(scores2d.device):
+        with _C.device_ctx(scores2d):
             _C.check(_C.lib().ltr_rank_by_score_f32(
                 _C.ptr(scores2d), _C.ptr(nn), B, L, _C.ptr(ranking), _C.stream_of(scores2d)))
     return ranking
@@ -74,7 +74,7 @@ def rank_by_score(
     :48-64).  Ties by index; the padded tail comes out in index order."""
     s = _prepare_scores(scores)
     nn = _prepare_n(n, s.shape[0])
-    max_l = _C.lib().ltr_max_list_len()
+    max_l = _C.max_list_len()
     if s.shape[1] > max_l:
         raise ValueError("list_size %d exceeds the supported maximum %d" % (s.shape[1], max_l))
     return _rank(s, nn)
@@ -92,7 +92,7 @@ def batch_pairs(x: _torch.Tensor) -> _torch.Tensor:
         raise TypeError("batch_pairs supports 4- and 8-byte dtypes, got %s" % x2.dtype)
     out = _torch.empty(B, L, L, 2, dtype=x2.dtype, device=x2.device)
     if B > 0 and L > 0:
-        with _torch.cuda.device(x2.device):
+        with _C.device_ctx(x2):
             _C.check(_C.lib().ltr_batch_pairs(_C.ptr(x2), esize, B, L, _C.ptr(out),
                                               _C.stream_of(x2)))
     return out

@@ -93,6 +93,32 @@ def test_fused_step_vs_reference_vectors(name):
         assert abs(float(db.cpu()[0]) - float(G.get(name, kind + "/db")[0])) < tol, kind
 
 
+def test_loss_sum_and_single_entry_point():
+    """ltr_linear_reduce_loss_f32 totals the loss in the reduction launch; the one-call entry
+    point ltr_linear_pairwise_f32 gives the same step."""
+    from pytorchltr_amd import _C
+    from pytorchltr_amd.fused import linear_loss_step
+    dev = _dev()
+    s, y, n, X, W, b = synth(40, 128, 21, F=136)
+    X, W, b, y, n = X.to(dev), W.to(dev), b.to(dev), y.to(dev), n.to(dev)
+    loss, dW, db, lsum = linear_loss_step(X, W, b, y, n, loss="logistic", return_loss_sum=True)
+    assert float(lsum) == pytest.approx(float(loss.double().sum()), rel=1e-5)
+    lib = _C.lib()
+    B, L, F = X.shape
+    ws_bytes = lib.ltr_linear_workspace_bytes(B, L, F)
+    ws = torch.empty(ws_bytes // 4, device=dev)
+    loss2, dW2, db2 = torch.empty(B, device=dev), torch.empty(F, device=dev), torch.empty(1, device=dev)
+    _C.check(lib.ltr_linear_pairwise_f32(_C.LOGISTIC, 1.0, X.data_ptr(), W.data_ptr(), b.data_ptr(),
+                                         y.data_ptr(), _C.LABEL_I64, n.data_ptr(), None, B, L, F,
+                                         loss2.data_ptr(), None, dW2.data_ptr(), db2.data_ptr(),
+                                         ws.data_ptr(), ws_bytes, _C.stream_of(X)))
+    assert torch.equal(loss, loss2) and torch.equal(dW, dW2) and torch.equal(db, db2)
+    assert lib.ltr_linear_pairwise_f32(_C.LOGISTIC, 1.0, X.data_ptr(), W.data_ptr(), b.data_ptr(),
+                                       y.data_ptr(), _C.LABEL_I64, n.data_ptr(), None, B, L, F,
+                                       loss2.data_ptr(), None, dW2.data_ptr(), db2.data_ptr(),
+                                       ws.data_ptr(), 16, _C.stream_of(X)) == -5      # workspace too small
+
+
 def test_fused_module_matches_unfused_dropin():
     """FusedLinearLoss == loss_fn(nn.Linear(F,1)(xs), ys, n) for arbitrary upstream weights."""
     from pytorchltr_amd.fused import FusedLinearLoss
