@@ -126,6 +126,21 @@ int ltr_mask_padded_values_f32(const float *xs, const int64_t *n, int B, int L,
 int ltr_batch_pairs(const void *x, int elem_bytes, int B, int L, void *out, void *stream);
 
 /*
+ * Device-side collate (the step immediately before the path): the dense branch of
+ * SVMRankDataset.collate_fn, datasets/svmrank/svmrank.py:126-207.  Ragged storage
+ *   xs (N, F) fp32, ys (N) int64, offsets (Q+1) int64 -- query q owns rows offsets[q]:offsets[q+1]
+ * and a batch of query indices qidx (B) become the zero-padded batch
+ *   out_x (B, L, F), out_y (B, L), out_n (B) = min(n_q, L).
+ * sel (B, L) int64 or NULL: document indices *within the query* to gather for the first
+ * min(n_q, L) slots (how a ListSampler truncates an over-long query, list_sampler.py:5-61);
+ * NULL means the first min(n_q, L) documents.  L is chosen by the caller (the reference uses
+ * max_i min(max_list_size, n_i)).
+ */
+int ltr_collate_pad_f32(const float *xs, const int64_t *ys, const int64_t *offsets,
+                        const int64_t *qidx, const int64_t *sel, int Q, int B, int L, int F,
+                        float *out_x, int64_t *out_y, int64_t *out_n, void *stream);
+
+/*
  * Linear scorer fused with the loss: the caller of the path in every reference workflow,
  *   loss_fn(torch.nn.Linear(F,1)(xs), ys, n)  ... .backward()
  * (examples/01-basic-usage.py:70-75, tests/test_integration.py:42-52).

@@ -937,6 +937,50 @@ __global__ void batch_pairs_kernel(const T *__restrict__ x, int L, T2 *__restric
 }
 
 // ---------------------------------------------------------------------------------
+// collate / pad (reference: SVMRankDataset.collate_fn dense path,
+// datasets/svmrank/svmrank.py:126-207): ragged rows + offsets -> zero-padded (B, L, F),
+// (B, L), n.  Pure gather/pad copy: one workgroup column per query, 16-byte vectors when F % 4
+// == 0, rows >= min(n_q, L) written as zeros, truncated queries gathered through `sel`.
+// ---------------------------------------------------------------------------------
+template <typename V>
+__global__ void collate_pad_kernel(const V *__restrict__ xs, const int64_t *__restrict__ ys,
+                                   const int64_t *__restrict__ offsets,
+                                   const int64_t *__restrict__ qidx,
+                                   const int64_t *__restrict__ sel, int Q, int L, int C,
+                                   V *__restrict__ out_x, int64_t *__restrict__ out_y,
+                                   int64_t *__restrict__ out_n)
+{
+    const int b = blockIdx.x;
+    int64_t q = qidx[b];
+    if (q < 0) q = 0;
+    if (q >= Q) q = Q - 1;
+    const int64_t off = offsets[q];
+    const int64_t cnt = offsets[q + 1] - off;
+    const int nout = (int)(cnt < (int64_t)L ? cnt : (int64_t)L);
+    const int64_t *srow = sel ? sel + (size_t)b * L : nullptr;
+    V zero;
+    memset(&zero, 0, sizeof(V));
+    const size_t total = (size_t)L * C;
+    V *ox = out_x + (size_t)b * total;
+    for (size_t e = (size_t)blockIdx.y * blockDim.x + threadIdx.x; e < total;
+         e += (size_t)gridDim.y * blockDim.x) {
+        const int l = (int)(e / (size_t)C);
+        const int c = (int)(e - (size_t)l * C);
+        V v = zero;
+        if (l < nout) {
+            const int64_t src = off + (srow ? srow[l] : (int64_t)l);
+            v = xs[(size_t)src * C + c];
+        }
+        ox[e] = v;
+    }
+    if (blockIdx.y == 0) {
+        for (int l = threadIdx.x; l < L; l += blockDim.x)
+            out_y[(size_t)b * L + l] = (l < nout) ? ys[off + (srow ? srow[l] : (int64_t)l)] : 0;
+        if (threadIdx.x == 0) out_n[b] = nout;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // host side: launch-shape heuristic and dispatch
 // ---------------------------------------------------------------------------------
 constexpr size_t kLdsBudget = 160 * 1024;
@@ -1218,6 +1262,30 @@ int ltr_batch_pairs(const void *x, int elem_bytes, int B, int L, void *out, void
         hipLaunchKernelGGL((batch_pairs_kernel<uint64_t, ulonglong2>), dim3(gx, (unsigned)B),
                            dim3(256), 0, (hipStream_t)stream, (const uint64_t *)x, L,
                            (ulonglong2 *)out);
+    return (int)hipGetLastError();
+}
+
+int ltr_collate_pad_f32(const float *xs, const int64_t *ys, const int64_t *offsets,
+                        const int64_t *qidx, const int64_t *sel, int Q, int B, int L, int F,
+                        float *out_x, int64_t *out_y, int64_t *out_n, void *stream)
+{
+    if (B < 0 || L <= 0 || F <= 0 || Q <= 0) return LTR_ERR_SHAPE;
+    if (B == 0) return LTR_OK;
+    if (!xs || !ys || !offsets || !qidx || !out_x || !out_y || !out_n) return LTR_ERR_NULL;
+    const bool vec = (F % 4 == 0) && (((uintptr_t)xs | (uintptr_t)out_x) % 16 == 0);
+    const int C = vec ? F / 4 : F;
+    const size_t per_query = (size_t)L * C;
+    unsigned gy = (unsigned)((per_query + 256 * 8 - 1) / (256 * 8));
+    if (gy < 1) gy = 1;
+    if (gy > 64) gy = 64;
+    const dim3 grid((unsigned)B, gy), block(256);
+    if (vec)
+        hipLaunchKernelGGL((collate_pad_kernel<float4>), grid, block, 0, (hipStream_t)stream,
+                           (const float4 *)xs, ys, offsets, qidx, sel, Q, L, C, (float4 *)out_x, out_y,
+                           out_n);
+    else
+        hipLaunchKernelGGL((collate_pad_kernel<float>), grid, block, 0, (hipStream_t)stream, xs, ys,
+                           offsets, qidx, sel, Q, L, C, out_x, out_y, out_n);
     return (int)hipGetLastError();
 }
 

@@ -1,0 +1,8 @@
+"""Data layer pieces adjacent to the hot path: list samplers and the
+device-side collate/padding of ragged query storage into the padded (B, L, F) batch the loss
+and metric kernels consume."""
+from pytorchltr_amd.datasets.list_sampler import ListSampler  # noqa: F401
+from pytorchltr_amd.datasets.list_sampler import UniformSampler  # noqa: F401
+from pytorchltr_amd.datasets.list_sampler import BalancedRelevanceSampler  # noqa: F401
+from pytorchltr_amd.datasets.ragged import RaggedQueries  # noqa: F401
+from pytorchltr_amd.datasets.ragged import SVMRankBatch  # noqa: F401

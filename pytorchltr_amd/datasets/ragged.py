@@ -1,0 +1,116 @@
+"""Device-side collate: ragged query storage -> padded batch, in one HIP launch.
+
+The reference pads a batch with a Python loop over samples on the host
+(``SVMRankDataset.collate_fn``, pytorchltr/datasets/svmrank/svmrank.py:126-207, dense path):
+``features (B, L, F)`` zero-padded, ``relevance (B, L)`` int64 zero-padded, ``n = min(n_i, L)``,
+``L = max_i min(max_list_size, n_i)``, over-long queries truncated by a ``ListSampler``.
+``RaggedQueries`` keeps the whole split on the GPU as concatenated rows plus offsets and
+produces the same batch with ``ltr_collate_pad_f32`` (a gather/pad copy at HBM speed); only the
+index vectors of truncated queries are drawn on the host, by the same sampler calls in the same
+order as the reference.
+"""
+from typing import List, Optional, Sequence
+
+import torch as _torch
+
+from pytorchltr_amd import _C
+from pytorchltr_amd.datasets.list_sampler import ListSampler
+
+
+class SVMRankBatch:
+    """Same fields as the reference's batch object (svmrank.py:30-40)."""
+
+    def __init__(self, features, relevance, n, qid, sparse=False):
+        self.features = features
+        self.relevance = relevance
+        self.n = n
+        self.qid = qid
+        self.sparse = sparse
+
+
+class RaggedQueries(_torch.utils.data.Dataset):
+    """A split of a learning-to-rank dataset resident on the device.
+
+    Args:
+        features: (N, F) float32, the documents of all queries, query after query.
+        relevance: (N,) int64 labels.
+        offsets: (Q + 1,) int64, documents of query q are rows offsets[q]:offsets[q+1].
+        qids: optional (Q,) int64 query ids (default 0..Q-1).
+        device: ROCm device the split lives on.
+    """
+
+    def __init__(self, features, relevance, offsets, qids=None, device="cuda"):
+        features = _torch.as_tensor(features, dtype=_torch.float32)
+        relevance = _torch.as_tensor(relevance, dtype=_torch.int64)
+        offsets = _torch.as_tensor(offsets, dtype=_torch.int64).cpu()
+        if features.dim() != 2 or relevance.dim() != 1 or features.shape[0] != relevance.shape[0]:
+            raise ValueError("features must be (N, F) and relevance (N,)")
+        if offsets.dim() != 1 or offsets.numel() < 1 or int(offsets[0]) != 0 or \
+                int(offsets[-1]) != features.shape[0] or bool((offsets[1:] < offsets[:-1]).any()):
+            raise ValueError("offsets must be non-decreasing, start at 0 and end at N")
+        self._q = offsets.numel() - 1
+        self._offsets_host = offsets
+        self._counts_host = offsets[1:] - offsets[:-1]
+        self._rel_host = relevance.cpu()                 # the samplers look at labels on the host
+        self._qids_host = (_torch.arange(self._q, dtype=_torch.int64) if qids is None
+                           else _torch.as_tensor(qids, dtype=_torch.int64).cpu())
+        dev = _torch.device(device)
+        self.features = features.to(dev).contiguous()
+        self.relevance = relevance.to(dev).contiguous()
+        self.offsets = offsets.to(dev)
+        _C.require_device(self.features, "features")
+
+    def __len__(self):
+        return self._q
+
+    def __getitem__(self, index):
+        """Items are just query indices: the batch is assembled on the device by collate."""
+        return int(index)
+
+    def query_relevance(self, index):
+        lo, hi = int(self._offsets_host[index]), int(self._offsets_host[index + 1])
+        return self._rel_host[lo:hi]
+
+    def plan(self, indices: Sequence[int], list_sampler: Optional[ListSampler] = None):
+        """Host part of a collate: list size and, for truncated queries, the sampled document
+        indices -- same calls in the same order as the reference's _collate_fn."""
+        if list_sampler is None:
+            list_sampler = ListSampler()
+        rels = [self.query_relevance(i) for i in indices]
+        list_size = max([list_sampler.max_list_size(r) for r in rels]) if rels else 0
+        select = None
+        for row, rel in enumerate(rels):
+            if rel.shape[0] > list_size:
+                picked = list_sampler(rel)
+                if select is None:
+                    select = _torch.arange(list_size, dtype=_torch.int64).repeat(len(rels), 1)
+                select[row, :picked.shape[0]] = picked
+        return list_size, select
+
+    def collate(self, indices: Sequence[int], list_sampler: Optional[ListSampler] = None) -> SVMRankBatch:
+        idx = _torch.as_tensor(list(indices), dtype=_torch.int64)
+        B = idx.numel()
+        list_size, select = self.plan(idx.tolist(), list_sampler)
+        dev = self.features.device
+        F = self.features.shape[1]
+        out_x = _torch.empty(B, list_size, F, dtype=_torch.float32, device=dev)
+        out_y = _torch.empty(B, list_size, dtype=_torch.int64, device=dev)
+        out_n = _torch.empty(B, dtype=_torch.int64, device=dev)
+        qidx = idx.to(dev)
+        sel = None if select is None else select.to(dev).contiguous()
+        if B > 0 and list_size > 0:
+            with _C.device_ctx(out_x):
+                _C.check(_C.lib().ltr_collate_pad_f32(
+                    _C.ptr(self.features), _C.ptr(self.relevance), _C.ptr(self.offsets),
+                    _C.ptr(qidx), _C.ptr(sel), self._q, B, list_size, F, _C.ptr(out_x),
+                    _C.ptr(out_y), _C.ptr(out_n), _C.stream_of(out_x)))
+        elif B > 0:
+            out_n.zero_()
+        qid = self._qids_host[idx].to(dev)
+        return SVMRankBatch(out_x, out_y, out_n, qid, False)
+
+    def collate_fn(self, list_sampler: Optional[ListSampler] = None):
+        """collate_fn for ``torch.utils.data.DataLoader(ragged, batch_size=..., collate_fn=...)``."""
+        def _collate(batch: List[int]) -> SVMRankBatch:
+            return self.collate(batch, list_sampler)
+        return _collate

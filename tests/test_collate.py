@@ -1,0 +1,129 @@
+"""Collate / list-sampler row.
+
+CPU tier: the list samplers (host code in the product, as in the reference) reproduce the
+reference's index vectors draw for draw; the numpy collate oracle reproduces the reference's
+padded batches; the host-side plan of RaggedQueries consumes the RNG exactly like the reference.
+GPU tier: ltr_collate_pad_f32 through RaggedQueries.collate == reference batch, bit-exact.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.collate_oracle import collate_dense
+from pytorchltr_amd.datasets.list_sampler import (BalancedRelevanceSampler, ListSampler,
+                                                  UniformSampler)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+V = np.load(os.path.join(HERE, "golden", "collate_vectors.npz"))
+with open(os.path.join(HERE, "golden", "collate_vectors.json")) as fh:
+    CASES = json.load(fh)["cases"]
+SAMPLERS = {"list": ListSampler, "uniform": UniformSampler, "balanced": BalancedRelevanceSampler}
+
+
+def _sampler(case):
+    kw = {}
+    if case["sampler"] != "list" and case["seed"] is not None:
+        kw["generator"] = torch.Generator().manual_seed(case["seed"])
+    return SAMPLERS[case["sampler"]](case["max_list_size"], **kw)
+
+
+def _split(case):
+    s = case["split"]
+    return V[s + "/xs"], V[s + "/ys"], V[s + "/offsets"], V[s + "/qids"]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_samplers_and_oracle_match_reference(case):
+    xs, ys, offsets, qids = _split(case)
+    name = case["name"]
+    indices = V[name + "/indices"].tolist()
+    calls = [V[name + "/call%d" % k] for k in range(case["n_calls"])]
+    # (1) oracle collate == reference batch, given the reference's sampler outputs
+    ox, oy, on = collate_dense(xs, ys, offsets, indices, calls, case["max_list_size"])
+    assert np.array_equal(ox, V[name + "/features"])
+    assert np.array_equal(oy, V[name + "/relevance"])
+    assert np.array_equal(on, V[name + "/n"])
+    # (2) our samplers, seeded like the reference's, draw the same index vectors in the same order
+    sampler = _sampler(case)
+    sizes = [sampler.max_list_size(torch.as_tensor(ys[offsets[q]:offsets[q + 1]])) for q in indices]
+    list_size = max(sizes)
+    assert list_size == V[name + "/features"].shape[1]
+    k = 0
+    for q in indices:
+        rel = torch.as_tensor(ys[offsets[q]:offsets[q + 1]])
+        if rel.shape[0] > list_size:
+            got = sampler(rel).numpy()
+            assert np.array_equal(got, calls[k]), (name, k)
+            k += 1
+    assert k == case["n_calls"]
+
+
+def test_sampler_contracts():
+    rel = torch.tensor([0, 0, 0, 0, 1, 1, 2, 0, 0, 0])
+    assert ListSampler().max_list_size(rel) == 10 and ListSampler(4).max_list_size(rel) == 4
+    assert ListSampler(4)(rel).tolist() == [0, 1, 2, 3]
+    g = torch.Generator().manual_seed(0)
+    u = UniformSampler(6, generator=g)(rel)
+    assert len(set(u.tolist())) == 6 and all(0 <= i < 10 for i in u.tolist())
+    b = BalancedRelevanceSampler(3, generator=torch.Generator().manual_seed(1))(rel)
+    assert sorted(rel[b].tolist()) == [0, 1, 2]                   # one document per grade
+    b = BalancedRelevanceSampler(100, generator=torch.Generator().manual_seed(1))(rel)
+    assert sorted(b.tolist()) == list(range(10))                  # everything survives a huge limit
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_device_collate_matches_reference(case):
+    from pytorchltr_amd.datasets import RaggedQueries
+    assert torch.cuda.is_available()
+    xs, ys, offsets, qids = _split(case)
+    name = case["name"]
+    ragged = RaggedQueries(xs, ys, offsets, qids, device="cuda:0")
+    batch = ragged.collate(V[name + "/indices"].tolist(), _sampler(case))
+    assert batch.sparse is False
+    assert batch.features.dtype == torch.float32 and batch.relevance.dtype == torch.int64
+    assert np.array_equal(batch.features.cpu().numpy(), V[name + "/features"])      # bit-exact
+    assert np.array_equal(batch.relevance.cpu().numpy(), V[name + "/relevance"])
+    assert np.array_equal(batch.n.cpu().numpy(), V[name + "/n"])
+    assert np.array_equal(batch.qid.cpu().numpy(), V[name + "/qid"])
+
+
+@pytest.mark.gpu
+def test_dataloader_training_loop_on_device_collate():
+    """The reference's loop shape (examples/01-basic-usage.py:66-75) with the batch assembled on
+    the device: DataLoader over query indices, collate_fn from RaggedQueries, loss + ndcg."""
+    from pytorchltr_amd.datasets import RaggedQueries, UniformSampler as US
+    from pytorchltr_amd.evaluation import ndcg
+    from pytorchltr_amd.loss import PairwiseHingeLoss
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(3)
+    counts = torch.randint(5, 60, (40,), generator=g)
+    offsets = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)])
+    xs = torch.randn(int(offsets[-1]), 16, generator=g)
+    w = torch.randn(16, generator=g)
+    ys = ((xs @ w) > 0.3).long() + ((xs @ w) > 1.2).long()
+    ragged = RaggedQueries(xs, ys, offsets, device="cuda:0")
+    loader = torch.utils.data.DataLoader(ragged, batch_size=8, shuffle=True,
+                                         collate_fn=ragged.collate_fn(US(max_list_size=32)))
+    model = torch.nn.Linear(16, 1).cuda()
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    loss_fn = PairwiseHingeLoss()
+
+    def evaluate():
+        tot = 0.0
+        with torch.no_grad():
+            for b in torch.utils.data.DataLoader(ragged, batch_size=8, collate_fn=ragged.collate_fn()):
+                tot += float(ndcg(model(b.features), b.relevance, b.n, k=10).sum())
+        return tot / len(ragged)
+
+    before = evaluate()
+    for _ in range(5):
+        for batch in loader:
+            assert batch.features.shape[1] <= 32 and int(batch.n.max()) <= 32
+            opt.zero_grad()
+            loss_fn(model(batch.features), batch.relevance, batch.n).mean().backward()
+            opt.step()
+    assert evaluate() > before + 0.05
