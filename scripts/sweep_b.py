@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""B-sweep of the two headline kernels at the C2 shape (list_len 128, 136 features): the
+B = 1024 batch of BASELINE.json is launch/latency dominated; this shows where the kernels land
+when the grid is large enough to be throughput-bound."""
+import os, sys, json, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import time_launches
+from pytorchltr_amd import _C
+dev = torch.device("cuda:0")
+lib = _C.lib()
+L, F = 128, 136
+rows = []
+for kind_name, kind in (("hinge", _C.HINGE), ("ndcg2", _C.NDCG2)):
+    for full in (False, True):
+        for B in (256, 1024, 4096, 16384, 65536, 262144):
+            g = torch.Generator().manual_seed(0)
+            scores = torch.randn(B, L, generator=g).to(dev)
+            rel = torch.randint(0, 5, (B, L), generator=g).to(dev)
+            n = (torch.full((B,), L) if full else torch.randint(1, L + 1, (B,), generator=g)).to(dev)
+            X = torch.randn(B, L, F, device=dev)
+            W = torch.randn(F, device=dev) * 0.1
+            bias = torch.zeros(1, device=dev)
+            loss = torch.empty(B, device=dev)
+            ds = torch.empty(B, L, device=dev)
+            part = torch.empty(lib.ltr_linear_workspace_bytes(B, L, F) // 4, device=dev)
+            cs = lambda: torch.cuda.current_stream().cuda_stream
+
+            def fused():
+                _C.check(lib.ltr_linear_partials_f32(kind, 1.0, X.data_ptr(), W.data_ptr(), bias.data_ptr(),
+                                                     rel.data_ptr(), 0, n.data_ptr(), B, L, F, loss.data_ptr(),
+                                                     None, part.data_ptr(), cs()))
+
+            def lossk():
+                _C.check(lib.ltr_pairwise_loss_f32(kind, 1.0, scores.data_ptr(), rel.data_ptr(), 0, n.data_ptr(),
+                                                   B, L, loss.data_ptr(), ds.data_ptr(), cs()))
+            reps = 10 if B <= 16384 else 3
+            per = 20 if B <= 16384 else 4
+            for _ in range(3):
+                fused(); lossk()
+            tf, _ = time_launches(fused, per_graph=per, replays=reps)
+            tl, _ = time_launches(lossk, per_graph=per, replays=reps)
+            alg_f = B * (4 * L * F + 8 * L + 12 + 4 * (F + 1))
+            real_f = int(n.sum()) * (4 * F + 8) + B * (12 + 4 * (F + 1))
+            alg_l = B * (16 * L + 16)
+            rows.append(dict(kind=kind_name, full_lists=full, B=B, fused_us=tf, fused_qps=B / tf * 1e6,
+                             fused_alg_GBs=alg_f / tf / 1e3, fused_read_GBs=real_f / tf / 1e3,
+                             loss_us=tl, loss_qps=B / tl * 1e6, loss_alg_GBs=alg_l / tl / 1e3))
+            print(json.dumps(rows[-1]), flush=True)
+            del X
