@@ -1,0 +1,122 @@
+"""GPU tier: limits and odd shapes -- maximum list length, huge batches, degenerate feature
+widths, extreme n -- against the oracle (small B) or through invariants (huge B)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ltr_oracle as O
+from tests.conftest import synth
+from tests.test_gpu_parity import _check_grad, _check_loss, _run_direct
+
+pytestmark = pytest.mark.gpu
+KINDS = list(O.KINDS)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_maximum_list_length(kind):
+    """list_len = ltr_max_list_len() = 4096: one workgroup's LDS, both-ends pass."""
+    from pytorchltr_amd import _C
+    L = _C.lib().ltr_max_list_len()
+    s, y, n = synth(2, L, 23)
+    n[0] = L
+    n[1] = L // 3
+    loss, ds = _run_direct(kind, s.numpy(), y.numpy(), n.numpy())
+    want_l, want_g = O.pairwise_loss(kind, s.numpy(), y.numpy(), n.numpy())
+    rtol = 2e-3 if kind in ("ndcg1", "ndcg2") else 5e-4          # ~1.7e7 fp32 terms per query
+    assert np.allclose(loss, want_l, rtol=rtol, atol=1e-5)
+    scale = np.max(np.abs(want_g), axis=1, keepdims=True)
+    assert np.all(np.abs(ds - want_g) <= 2e-4 * scale + 1e-5)
+    if kind == "hinge":
+        assert np.array_equal(ds, want_g)
+
+
+def test_list_too_long_is_an_error():
+    import pytorchltr_amd.loss as losses
+    dev = torch.device("cuda:0")
+    with pytest.raises(ValueError, match="exceeds"):
+        losses.PairwiseHingeLoss()(torch.zeros(1, 5000, device=dev),
+                                   torch.zeros(1, 5000, dtype=torch.long, device=dev),
+                                   torch.tensor([5000], device=dev))
+
+
+@pytest.mark.parametrize("kind", ["hinge", "ndcg2"])
+def test_huge_batch_of_short_lists(kind):
+    """B = 200k queries of 8 documents: grid-size and indexing limits; spot rows vs oracle."""
+    B, L = 200_000, 8
+    s, y, n = synth(B, L, 31)
+    loss, ds = _run_direct(kind, s.numpy(), y.numpy(), n.numpy())
+    rows = np.r_[0:50, B - 50:B, B // 2:B // 2 + 50]
+    want_l, want_g = O.pairwise_loss(kind, s.numpy()[rows], y.numpy()[rows], n.numpy()[rows])
+    _check_loss(loss[rows], want_l, L, kind)
+    _check_grad(ds[rows], want_g, kind, exact=(kind == "hinge"))
+    assert np.all(np.isfinite(loss)) and np.all(np.isfinite(ds))
+
+
+def test_metrics_on_huge_batch_and_long_lists():
+    import pytorchltr_amd.evaluation as ev
+    dev = torch.device("cuda:0")
+    s, y, n = synth(50_000, 20, 5)
+    y = y * (torch.arange(20)[None, :] < n[:, None])
+    got = ev.ndcg(s.to(dev), y.to(dev), n.to(dev), k=10).cpu().numpy()
+    rows = np.r_[0:40, 49_960:50_000]
+    assert np.allclose(got[rows], O.ndcg(s.numpy()[rows], y.numpy()[rows], n.numpy()[rows], k=10),
+                       rtol=2e-6, atol=1e-6)
+    s, y, n = synth(3, 4096, 6)
+    y = y * (torch.arange(4096)[None, :] < n[:, None])
+    for fn, ofn in ((ev.dcg, O.dcg), (ev.ndcg, O.ndcg)):
+        curve = fn(s.to(dev), y.to(dev), n.to(dev)).cpu().numpy()
+        assert np.allclose(curve, ofn(s.numpy(), y.numpy(), n.numpy()), rtol=5e-5, atol=1e-5)
+    assert np.allclose(ev.arp(s.to(dev), y.to(dev), n.to(dev)).cpu().numpy(),
+                       O.arp(s.numpy(), y.numpy(), n.numpy()), rtol=2e-5)
+
+
+@pytest.mark.parametrize("F", [1, 2, 3, 7, 4, 8, 500, 1023, 1024, 2048, 2052, 4100])
+def test_fused_step_feature_widths(F):
+    """Scalar path (F % 4 != 0), vector path, one column, very wide rows."""
+    from pytorchltr_amd.fused import linear_loss_step
+    dev = torch.device("cuda:0")
+    B, L = 5, 19
+    s, y, n, X, W, b = synth(B, L, 40 + F, F=F)
+    for kind in ("hinge", "arp1"):
+        loss, dW, db = linear_loss_step(X.to(dev), W.to(dev), b.to(dev), y.to(dev), n.to(dev), loss=kind)
+        want_l, _, want_dW, want_db = O.linear_pairwise(kind, X.numpy(), W.numpy(), float(b[0]), y.numpy(),
+                                                        n.numpy(), np.full(B, 1.0 / B))
+        assert np.allclose(loss.cpu().numpy(), want_l, rtol=5e-5, atol=1e-5), (kind, F)
+        tol = 5e-5 * max(1.0, float(np.max(np.abs(want_dW))))
+        assert np.max(np.abs(dW.cpu().numpy() - want_dW)) < tol, (kind, F)
+        assert abs(float(db.cpu()[0]) - want_db) < tol
+
+
+def test_fused_step_too_wide_is_an_error():
+    """The weight vector must fit one workgroup's LDS next to the query block."""
+    from pytorchltr_amd.fused import linear_loss_step
+    dev = torch.device("cuda:0")
+    F = 60000
+    X = torch.zeros(1, 4, F, device=dev)
+    with pytest.raises(RuntimeError, match="shape"):
+        linear_loss_step(X, torch.zeros(F, device=dev), torch.zeros(1, device=dev),
+                         torch.zeros(1, 4, dtype=torch.long, device=dev), torch.tensor([4], device=dev))
+
+
+def test_extreme_n_values_and_nonfinite_padding():
+    """n far outside [0, L], int64 extremes; inf/NaN garbage in padded slots must not leak."""
+    s, y, n = synth(6, 40, 77)
+    n = torch.tensor([-(2 ** 62), -1, 0, 40, 41, 2 ** 62])
+    s2 = s.clone()
+    s2[3:, :] = s[3:, :]
+    for kind in KINDS:
+        loss, ds = _run_direct(kind, s2.numpy(), y.numpy(), n.numpy())
+        want_l, want_g = O.pairwise_loss(kind, s2.numpy(), y.numpy(), n.numpy())
+        _check_loss(loss, want_l, 40, kind)
+        _check_grad(ds, want_g, kind, exact=(kind == "hinge"))
+    s3, y3, n3 = synth(4, 40, 78)
+    pad = torch.arange(40)[None, :] >= n3[:, None]
+    s4 = s3.clone()
+    s4[pad] = float("nan")
+    s5 = s3.clone()
+    s5[pad] = float("inf")
+    for kind in KINDS:
+        base = _run_direct(kind, s3.numpy(), y3.numpy(), n3.numpy())
+        for other in (s4, s5):
+            got = _run_direct(kind, other.numpy(), y3.numpy(), n3.numpy())
+            assert np.array_equal(base[0], got[0]) and np.array_equal(base[1], got[1]), kind
