@@ -96,6 +96,17 @@ int ltr_pairwise_loss_f32_cfg(int kind, float sigma, const float *scores, const 
 int ltr_scale_rows_f32(const float *dscores, const float *grad_out, int B, int L, float *out,
                        void *stream);
 
+/*
+ * Double-precision instantiation of the two entry points above.  The reference computes in the
+ * dtype of `scores` (fp64 in -> fp64 out), which `torch.autograd.gradcheck` users rely on.
+ * Straightforward kernels, not tuned (fp64 VALU is half rate, no f64 transcendentals).
+ */
+int ltr_pairwise_loss_f64(int kind, double sigma, const double *scores, const void *rel,
+                          int rel_dtype, const int64_t *n, int B, int L, double *loss,
+                          double *dscores, void *stream);
+int ltr_scale_rows_f64(const double *dscores, const double *grad_out, int B, int L, double *out,
+                       void *stream);
+
 /* rank_by_score, utils/tensor_operations.py:48-64 (mask_padded_values :6-26 +
  * tiebreak_argsort :29-45).  ranking[b,r] = index of the document at rank r (int64). */
 int ltr_rank_by_score_f32(const float *scores, const int64_t *n, int B, int L,

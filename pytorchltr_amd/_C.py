@@ -26,6 +26,8 @@ SIGNATURES = {
     "ltr_pairwise_loss_f32": (_i, [_i, _f, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "ltr_pairwise_loss_f32_cfg": (_i, [_i, _f, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     "ltr_scale_rows_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "ltr_pairwise_loss_f64": (_i, [_i, ctypes.c_double, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
+    "ltr_scale_rows_f64": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "ltr_rank_by_score_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "ltr_dcg_f32": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ltr_arp_f32": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),

@@ -12,35 +12,37 @@ class PairwiseLossFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, scores, relevance, n, kind, sigma):
-        s, r, nn = prepare(scores, relevance, n)
+        s, r, nn = prepare(scores, relevance, n, allow_f64=True)
         B, L = s.shape
         need_grad = ctx.needs_input_grad[0]
-        loss = torch.empty(B, dtype=torch.float32, device=s.device)
-        ds = torch.empty(B, L, dtype=torch.float32, device=s.device) if need_grad else None
+        f64 = s.dtype == torch.float64          # fp64 in -> fp64 arithmetic, like the reference
+        loss = torch.empty(B, dtype=s.dtype, device=s.device)
+        ds = torch.empty(B, L, dtype=s.dtype, device=s.device) if need_grad else None
         if B > 0:
+            entry = _C.lib().ltr_pairwise_loss_f64 if f64 else _C.lib().ltr_pairwise_loss_f32
             with _C.device_ctx(s):
-                _C.check(_C.lib().ltr_pairwise_loss_f32(
-                    kind, float(sigma), _C.ptr(s), _C.ptr(r), _C.label_dtype(r), _C.ptr(nn),
-                    B, L, _C.ptr(loss), _C.ptr(ds), _C.stream_of(s)))
+                _C.check(entry(kind, float(sigma), _C.ptr(s), _C.ptr(r), _C.label_dtype(r),
+                               _C.ptr(nn), B, L, _C.ptr(loss), _C.ptr(ds), _C.stream_of(s)))
         if need_grad:
             ctx.save_for_backward(ds)
         ctx.in_shape = scores.shape
         ctx.in_dtype = scores.dtype
-        return loss if scores.dtype == torch.float32 else loss.to(scores.dtype)
+        return loss if scores.dtype == loss.dtype else loss.to(scores.dtype)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out):
         (ds,) = ctx.saved_tensors
         B, L = ds.shape
-        go = grad_out.reshape(B).float().contiguous()
+        go = grad_out.reshape(B).to(ds.dtype).contiguous()
         out = torch.empty_like(ds)
         if B > 0:
+            entry = (_C.lib().ltr_scale_rows_f64 if ds.dtype == torch.float64
+                     else _C.lib().ltr_scale_rows_f32)
             with _C.device_ctx(ds):
-                _C.check(_C.lib().ltr_scale_rows_f32(
-                    _C.ptr(ds), _C.ptr(go), B, L, _C.ptr(out), _C.stream_of(ds)))
+                _C.check(entry(_C.ptr(ds), _C.ptr(go), B, L, _C.ptr(out), _C.stream_of(ds)))
         out = out.reshape(ctx.in_shape)
-        if ctx.in_dtype != torch.float32:
+        if ctx.in_dtype != out.dtype:
             out = out.to(ctx.in_dtype)
         return out, None, None, None, None
 

@@ -21,11 +21,17 @@ def as_2d(t, what):
 def prepare_scores(scores):
     _C.require_device(scores, "scores")
     s = as_2d(scores, "scores")
-    if s.dtype != torch.float32:
+    if s.dtype not in (torch.float32, torch.float64):
         if not s.dtype.is_floating_point:
             raise TypeError("scores must be floating point, got %s" % s.dtype)
-        s = s.float()          # arithmetic is fp32 on the device; result is cast back
+        s = s.float()          # half / bfloat16: arithmetic is fp32, result is cast back
     return s.contiguous()
+
+
+def prepare_scores_f32(scores):
+    """fp32-only consumers (metrics, helpers, fused scorer)."""
+    s = prepare_scores(scores)
+    return s if s.dtype == torch.float32 else s.float()
 
 
 def prepare_relevance(relevance, like):
@@ -50,8 +56,8 @@ def prepare_n(n, batch):
     return n.contiguous()
 
 
-def prepare(scores, relevance, n):
-    s = prepare_scores(scores)
+def prepare(scores, relevance, n, allow_f64=False):
+    s = prepare_scores(scores) if allow_f64 else prepare_scores_f32(scores)
     r = prepare_relevance(relevance, s)
     nn = prepare_n(n, s.shape[0])
     if not (s.device == r.device == nn.device):

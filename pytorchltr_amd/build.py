@@ -12,7 +12,7 @@ _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libltr_hip.so")
 SOURCES = [os.path.join(CSRC, "ltr_kernels.hip")]
-DEPENDS = SOURCES + [os.path.join(CSRC, "ltr_linear.inc"),
+DEPENDS = SOURCES + [os.path.join(CSRC, "ltr_linear.inc"), os.path.join(CSRC, "ltr_f64.inc"),
                      os.path.join(_ROOT, "include", "ltr_hip.h")]
 ARCH = "gfx950"
 

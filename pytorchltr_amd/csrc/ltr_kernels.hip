@@ -1292,3 +1292,4 @@ int ltr_collate_pad_f32(const float *xs, const int64_t *ys, const int64_t *offse
 }  // extern "C"
 
 #include "ltr_linear.inc"
+#include "ltr_f64.inc"

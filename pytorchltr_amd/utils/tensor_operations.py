@@ -10,7 +10,7 @@ import torch as _torch
 from pytorchltr_amd import _C
 from pytorchltr_amd._prepare import as_2d as _as_2d
 from pytorchltr_amd._prepare import prepare_n as _prepare_n
-from pytorchltr_amd._prepare import prepare_scores as _prepare_scores
+from pytorchltr_amd._prepare import prepare_scores_f32 as _prepare_scores
 
 
 def mask_padded_values(xs: _torch.FloatTensor, n: _torch.LongTensor,

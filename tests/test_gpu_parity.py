@@ -337,3 +337,53 @@ def test_argument_errors_are_loud():
     a = losses.LambdaNDCGLoss2()(s.to(dev), y.to(dev), n.to(dev))
     b = losses.LambdaNDCGLoss2()(s.to(dev), y.float().to(dev), n.int().to(dev))
     assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------
+# fp64: the reference computes in the dtype of `scores` (fp64 in -> fp64 out)
+# ---------------------------------------------------------------------------------------
+_LOSS_CLS = None
+
+
+def _loss_cls(kind):
+    import pytorchltr_amd.loss as losses
+    return {"hinge": losses.PairwiseHingeLoss, "dcg_hinge": losses.PairwiseDCGHingeLoss,
+            "logistic": losses.PairwiseLogisticLoss, "arp1": losses.LambdaARPLoss1,
+            "arp2": losses.LambdaARPLoss2, "ndcg1": losses.LambdaNDCGLoss1,
+            "ndcg2": losses.LambdaNDCGLoss2}[kind]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_fp64_scores_give_fp64_arithmetic(kind):
+    dev = _dev()
+    for (B, L, seed) in ((6, 40, 3), (3, 300, 4)):
+        s, y, n = synth(B, L, seed)
+        sc = s.double().to(dev).requires_grad_(True)
+        out = _loss_cls(kind)()(sc, y.to(dev), n.to(dev))
+        assert out.dtype == torch.float64
+        out.sum().backward()
+        assert sc.grad.dtype == torch.float64
+        want_l, want_g = O.pairwise_loss(kind, s.double().numpy(), y.numpy(), n.numpy())
+        assert np.allclose(out.detach().cpu().numpy(), want_l, rtol=1e-11, atol=1e-12), kind
+        scale = np.max(np.abs(want_g), axis=1, keepdims=True) + 1e-300
+        assert np.all(np.abs(sc.grad.cpu().numpy() - want_g) <= 1e-11 * scale + 1e-13), kind
+        # and it agrees with the reference's own fp64 run where that was captured
+    name = "syn_b8_l16"
+    s, y, n = G.inputs(name)
+    sc = torch.as_tensor(s).double().to(dev).requires_grad_(True)
+    out = _loss_cls(kind)()(sc, torch.as_tensor(y).to(dev), torch.as_tensor(n).to(dev))
+    out.sum().backward()
+    tol = 1e-6 if kind in ("ndcg1", "ndcg2") else 1e-11      # the reference keeps fp32 tables there
+    assert np.allclose(out.detach().cpu().numpy(), G.get(name, kind + "/loss64"), rtol=tol, atol=1e-12)
+    assert np.allclose(sc.grad.cpu().numpy(), G.get(name, kind + "/grad64").reshape(8, 16), rtol=10 * tol, atol=1e-9)
+
+
+@pytest.mark.parametrize("kind", ["logistic", "arp1", "arp2", "ndcg1", "ndcg2"])
+def test_gradcheck_in_double(kind):
+    """torch.autograd.gradcheck: analytic backward vs numerical Jacobian, in fp64."""
+    dev = _dev()
+    s, y, n = synth(3, 9, 12)
+    sc = s.double().to(dev).requires_grad_(True)
+    fn = _loss_cls(kind)(sigma=1.3)
+    assert torch.autograd.gradcheck(lambda t: fn(t, y.to(dev), n.to(dev)), (sc,), eps=1e-6, atol=1e-7,
+                                    rtol=1e-6, nondet_tol=0.0)
