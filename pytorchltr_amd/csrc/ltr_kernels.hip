@@ -526,13 +526,17 @@ __device__ __forceinline__ float pairwise_core_sym(const QueryLds &q, int nb, in
     for (int i = lane; i < 64 * nt; i += 64) gw[i] = 0.f;
 
     float lacc = 0.f;
-    const int S = 32 * nt * nt;
+    // Steps per job: off-diagonal 64 (j = 0..63); diagonal 32 (j = 1..32), except that the last,
+    // partially filled tile only has pairs at j < hc (hc = its document count) while hc <= 32.
+    const int hc_last = nb - 64 * (nt - 1);
+    const int dlast = (hc_last - 1 < 32) ? (hc_last - 1) : 32;
+    const int S = (nt > 0) ? (32 * nt * nt - (32 - dlast)) : 0;
     int u = (w * S) / W;
     const int u1 = ((w + 1) * S) / W;
     // decode the first unit of this wave into (a, b, j)
     int a = 0, b = 0, rem = u;
     while (a < nt) {
-        const int len = (a == b) ? 32 : 64;
+        const int len = (a == b) ? ((a == nt - 1) ? dlast : 32) : 64;
         if (rem < len) break;
         rem -= len;
         if (++b == nt) { ++a; b = a; }
@@ -541,7 +545,7 @@ __device__ __forceinline__ float pairwise_core_sym(const QueryLds &q, int nb, in
 
     while (u < u1) {
         const bool diag = (a == b);
-        const int jend = diag ? 33 : 64;
+        const int jend = diag ? (1 + ((a == nt - 1) ? dlast : 32)) : 64;
         // ---- load the home tile and the visitor tile (rotated by j) of this segment ----
         const int hidx = 64 * a + lane;
         const bool hvalid = hidx < nb;
@@ -626,12 +630,13 @@ __device__ __forceinline__ float pairwise_core_sym(const QueryLds &q, int nb, in
             const int fidx = 64 * b + ((lane + j) & 63);         // the visitor now in this lane
             if (fidx < nb) gw[fidx] += gv;
         }
-        if (kRowWeight && diag && j == jend && hvalid) lacc += yh;   // the i == j terms: a_i * log2(2)
         if (j == jend) {
             if (++b == nt) { ++a; b = a; }
             j = (a == b) ? 1 : 0;
         }
     }
+    if (kRowWeight)                           // the i == j terms: a_i * log2(1 + e^0) = a_i
+        for (int k = tid; k < nb; k += T) lacc += q.sy[k].y;
 
     float total = block_sum(lacc, q.red);     // its barriers publish gpart when there are >= 2 waves
     if (T == kWave) __syncthreads();
