@@ -137,6 +137,25 @@ int ltr_mask_padded_values_f32(const float *xs, const int64_t *n, int B, int L,
 int ltr_batch_pairs(const void *x, int elem_bytes, int B, int L, void *out, void *stream);
 
 /*
+ * Plackett-Luce sampling keys (rank_by_plackettluce, utils/tensor_operations.py:67-91):
+ *   keys[b,j] = log_softmax(masked scores)[b,j] - log(-log(u[b,j]))  for j < n[b], -inf after;
+ * the sampled ranking is ltr_rank_by_score_f32(keys, n) (descending keys == ascending
+ * log(-log u) - log p).  u is a caller-supplied uniform(0,1) tensor (B, L).
+ */
+int ltr_plackettluce_keys_f32(const float *scores, const int64_t *n, const float *u, int B, int L,
+                              float *keys, void *stream);
+
+/*
+ * Position-based-model click simulator (simulate_pbm, click_simulation/pbm.py:12-63).
+ * rankings (B,L) int64, ys (B,L) int64 labels, relevance_probs (n_probs) fp32 click probability
+ * per label, u (B,L) uniform(0,1) indexed by RANK, cutoff < 0 = none, eta = position-bias
+ * severity.  clicks (B,L) int64 in {0,1} and propensities (B,L) fp32, both in DOCUMENT order.
+ */
+int ltr_pbm_clicks(const int64_t *rankings, const int64_t *ys, const int64_t *n,
+                   const float *relevance_probs, int n_probs, const float *u, int B, int L,
+                   int cutoff, float eta, int64_t *clicks, float *propensities, void *stream);
+
+/*
  * Device-side collate (the step immediately before the path): the dense branch of
  * SVMRankDataset.collate_fn, datasets/svmrank/svmrank.py:126-207.  Ragged storage
  *   xs (N, F) fp32, ys (N) int64, offsets (Q+1) int64 -- query q owns rows offsets[q]:offsets[q+1]

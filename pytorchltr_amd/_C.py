@@ -33,6 +33,8 @@ SIGNATURES = {
     "ltr_arp_f32": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
     "ltr_mask_padded_values_f32": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp]),
     "ltr_batch_pairs": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "ltr_plackettluce_keys_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "ltr_pbm_clicks": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
     "ltr_collate_pad_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ltr_linear_workspace_bytes": (_sz, [_i, _i, _i]),
     "ltr_linear_pairwise_f32": (_i, [_i, _f, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i,

@@ -942,6 +942,74 @@ __global__ void batch_pairs_kernel(const T *__restrict__ x, int L, T2 *__restric
 }
 
 // ---------------------------------------------------------------------------------
+// Plackett-Luce sampling keys and the PBM click simulator (both sit on the
+// rank kernel).  Randomness comes in as a uniform(0,1) tensor from the caller (torch's device
+// Philox generator), so both kernels are deterministic functions of their inputs.
+// ---------------------------------------------------------------------------------
+// rank_by_plackettluce, utils/tensor_operations.py:67-91: r = log(-log u) - log_softmax(masked
+// scores); the sampled ranking is the ASCENDING argsort of r.  Writes key = -r (so the
+// descending rank kernel applies), row by row; padded documents are masked by the rank kernel.
+__global__ void __launch_bounds__(256)
+plackettluce_keys_kernel(const float *__restrict__ scores, const int64_t *__restrict__ n,
+                         const float *__restrict__ u, int L, float *__restrict__ keys)
+{
+    __shared__ float red[8];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int nb = clamp_n(n[b], L);
+    const size_t row = (size_t)b * L;
+    float mx = -INFINITY;
+    for (int j = tid; j < nb; j += 256) mx = fmaxf(mx, scores[row + j]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, kWave));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float se = 0.f;
+    for (int j = tid; j < nb; j += 256) se += expf(scores[row + j] - mx);
+    se = wave_sum(se);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = se;
+    __syncthreads();
+    const float lse = mx + logf((red[4] + red[5]) + (red[6] + red[7]));
+    for (int j = tid; j < L; j += 256) {
+        float key = -INFINITY;
+        if (j < nb) key = (scores[row + j] - lse) - logf(-logf(u[row + j]));
+        keys[row + j] = key;
+    }
+}
+
+// simulate_pbm, click_simulation/pbm.py:12-63.  For rank position r of query b:
+//   obs = r < min(n, cutoff) ? 1 / (r + 2)^eta : 0;   doc = rankings[b, r];
+//   click = u[b, r] < relevance_probs[ys[b, doc]] * obs;
+// clicks and propensities are written at the DOCUMENT's slot (the reference's final gather
+// through the inverted ranking, :57-63).
+__global__ void pbm_clicks_kernel(const int64_t *__restrict__ rankings, const int64_t *__restrict__ ys,
+                                  const int64_t *__restrict__ n, const float *__restrict__ rel_probs,
+                                  int n_probs, const float *__restrict__ u, size_t total, int L,
+                                  int cutoff, float eta, int64_t *__restrict__ clicks,
+                                  float *__restrict__ props)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const size_t b = i / (size_t)L;
+        const int r = (int)(i - b * (size_t)L);
+        int64_t lim = n[b];
+        if (cutoff >= 0 && (int64_t)cutoff < lim) lim = cutoff;
+        const float obs = ((int64_t)r < lim) ? powf(1.0f / (2.0f + (float)r), eta) : 0.0f;
+        int64_t doc = rankings[i];
+        if (doc < 0) doc = 0;
+        if (doc >= L) doc = L - 1;
+        int64_t y = ys[b * (size_t)L + doc];
+        if (y < 0) y = 0;
+        if (y >= n_probs) y = n_probs - 1;
+        const float pclick = rel_probs[y] * obs;
+        clicks[b * (size_t)L + doc] = (u[i] < pclick) ? 1 : 0;
+        props[b * (size_t)L + doc] = obs;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // collate / pad (reference: SVMRankDataset.collate_fn dense path,
 // datasets/svmrank/svmrank.py:126-207): ragged rows + offsets -> zero-padded (B, L, F),
 // (B, L), n.  Pure gather/pad copy: one workgroup column per query, 16-byte vectors when F % 4
@@ -1267,6 +1335,31 @@ int ltr_batch_pairs(const void *x, int elem_bytes, int B, int L, void *out, void
         hipLaunchKernelGGL((batch_pairs_kernel<uint64_t, ulonglong2>), dim3(gx, (unsigned)B),
                            dim3(256), 0, (hipStream_t)stream, (const uint64_t *)x, L,
                            (ulonglong2 *)out);
+    return (int)hipGetLastError();
+}
+
+int ltr_plackettluce_keys_f32(const float *scores, const int64_t *n, const float *u, int B, int L,
+                              float *keys, void *stream)
+{
+    if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
+    if (B == 0) return LTR_OK;
+    if (!scores || !n || !u || !keys) return LTR_ERR_NULL;
+    hipLaunchKernelGGL(plackettluce_keys_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                       scores, n, u, L, keys);
+    return (int)hipGetLastError();
+}
+
+int ltr_pbm_clicks(const int64_t *rankings, const int64_t *ys, const int64_t *n,
+                   const float *relevance_probs, int n_probs, const float *u, int B, int L,
+                   int cutoff, float eta, int64_t *clicks, float *propensities, void *stream)
+{
+    if (B < 0 || L <= 0 || n_probs <= 0) return LTR_ERR_SHAPE;
+    if (B == 0) return LTR_OK;
+    if (!rankings || !ys || !n || !relevance_probs || !u || !clicks || !propensities) return LTR_ERR_NULL;
+    const size_t total = (size_t)B * L;
+    hipLaunchKernelGGL(pbm_clicks_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       rankings, ys, n, relevance_probs, n_probs, u, total, L, cutoff, eta, clicks,
+                       propensities);
     return (int)hipGetLastError();
 }
 

@@ -80,6 +80,35 @@ def rank_by_score(
     return _rank(s, nn)
 
 
+def _plackettluce_from_uniform(scores, n, uniform):
+    """Deterministic core of the sampler: the ranking implied by one uniform(0,1) draw per
+    document (keys on the device, then the rank kernel)."""
+    s = _prepare_scores(scores)
+    nn = _prepare_n(n, s.shape[0])
+    B, L = s.shape
+    u = uniform.reshape(B, L).to(device=s.device, dtype=_torch.float32).contiguous()
+    keys = _torch.empty_like(s)
+    if B > 0:
+        with _C.device_ctx(s):
+            _C.check(_C.lib().ltr_plackettluce_keys_f32(_C.ptr(s), _C.ptr(nn), _C.ptr(u), B, L,
+                                                        _C.ptr(keys), _C.stream_of(s)))
+    return _rank(keys, nn)
+
+
+def rank_by_plackettluce(
+        scores: _torch.FloatTensor, n: _torch.LongTensor,
+        generator: Optional[_torch.Generator] = None) -> _torch.LongTensor:
+    """Samples a ranking from a Plackett-Luce distribution, padded documents last
+    (reference :67-91): sort ascending by log(-log u) - log_softmax(scores).
+
+    `generator`, if given, must be a generator of the scores' device."""
+    _C.require_device(scores, "scores")
+    shape = (scores.shape[0], scores.shape[1])
+    kw = {} if generator is None else {"generator": generator}
+    u = _torch.rand(shape, device=scores.device, dtype=_torch.float32, **kw)
+    return _plackettluce_from_uniform(scores, n, u)
+
+
 def batch_pairs(x: _torch.Tensor) -> _torch.Tensor:
     """Materialises all pairs: p[b,i,j,0] = x[b,i], p[b,i,j,1] = x[b,j] (reference :94-119).
 
