@@ -178,8 +178,8 @@ int ltr_collate_pad_f32(const float *xs, const int64_t *ys, const int64_t *offse
  *   dW (F) and db (1) = d( sum_b grad_out[b]*loss[b] ) / d{W, bias}.
  * grad_out (B) may be NULL, meaning 1/B for every query (`.mean().backward()`).
  * Rows l >= n[b] are never read (their gradient is 0) unless scores_out is requested; when
- * the (L x F) tile fits in LDS the features cross HBM exactly once.
- * `workspace` needs ltr_linear_workspace_bytes(B,L,F) bytes (per-query partials + scratch).
+ * the (L x F) tile fits one workgroup's registers the features cross HBM exactly once.
+ * `workspace` needs ltr_linear_workspace_bytes(B,L,F) bytes (per-query partials).
  */
 size_t ltr_linear_workspace_bytes(int B, int L, int F);
 int ltr_linear_pairwise_f32(int kind, float sigma, const float *X, const float *W,
@@ -192,8 +192,8 @@ int ltr_linear_pairwise_f32(int kind, float sigma, const float *X, const float *
  * Linear+loss module): partials is (F+1, B) row-major -- partials[f, b] = d loss[b] / dW_f for
  * f < F, partials[F, b] = d loss[b] / d bias -- so that the reduction over queries reads
  * contiguously; then dW_f = sum_b grad_out[b] * partials[f, b], db likewise (grad_out NULL = 1/B).
- * The `partials` buffer must be ltr_linear_workspace_bytes(B,L,F) bytes: the (F+1)*B matrix is
- * followed by a small scratch tail (work-queue ticket of the persistent kernel). */
+ * The `partials` buffer must be ltr_linear_workspace_bytes(B,L,F) bytes (the (F+1)*B matrix,
+ * rounded up, plus a reserved tail). */
 int ltr_linear_partials_f32(int kind, float sigma, const float *X, const float *W,
                             const float *bias, const void *rel, int rel_dtype,
                             const int64_t *n, int B, int L, int F, float *loss,

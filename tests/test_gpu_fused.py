@@ -39,7 +39,7 @@ def _check(kind, B, L, F, seed, sigma=1.0, full=False, grad_out=None):
     tol = 2e-5 * max(1.0, float(np.max(np.abs(want_dW)))) * (10 if L > 256 else 1)
     assert np.max(np.abs(dW.cpu().numpy() - want_dW)) < tol, kind
     assert abs(float(db.cpu()[0]) - want_db) < tol, kind
-    # without the score output the single-pass persistent (LDS-DMA) kernel is eligible
+    # without the score output the single-pass register-tile kernel is eligible
     loss2, dW2, db2 = linear_loss_step(X.to(dev), W.to(dev), b.to(dev), y.to(dev), n.to(dev),
                                        loss=loss_mod, grad_out=go)
     assert np.allclose(loss2.cpu().numpy(), want_l, rtol=rtol, atol=1e-5), kind
@@ -54,8 +54,8 @@ def test_fused_step_small_shapes(kind):
     _check(kind, 5, 64, 136, 6)                  # C2 feature width
 
 
-def test_persistent_kernel_many_queries_per_workgroup():
-    """B far above the resident workgroup count: every workgroup dequeues several queries."""
+def test_many_more_queries_than_resident_workgroups():
+    """B far above the resident workgroup count (several dispatch rounds per CU)."""
     _check("hinge", 2100, 24, 8, 13)
     _check("ndcg2", 1500, 40, 16, 14)
 
