@@ -1,4 +1,4 @@
-"""Build the HIP extension in-tree:  python -m pytorchltr_amd.build [--force]
+"""Build the native libraries in-tree:  python -m pytorchltr_amd.build [--force]
 
 Cross-compiles for gfx950 with hipcc (no GPU needed to build).  The resulting
 ``pytorchltr_amd/csrc/libltr_hip.so`` is git-ignored but travels with the tree.
@@ -15,6 +15,9 @@ SOURCES = [os.path.join(CSRC, "ltr_kernels.hip")]
 DEPENDS = SOURCES + [os.path.join(CSRC, "ltr_linear.inc"), os.path.join(CSRC, "ltr_f64.inc"),
                      os.path.join(_ROOT, "include", "ltr_hip.h")]
 ARCH = "gfx950"
+IO_LIB_PATH = os.path.join(CSRC, "libltr_io.so")
+IO_SOURCES = [os.path.join(CSRC, "svmrank_parser.cpp")]
+IO_DEPENDS = IO_SOURCES + [os.path.join(_ROOT, "include", "ltr_io.h")]
 
 
 def _hipcc():
@@ -45,6 +48,20 @@ def build_extension(force=False, verbose=False):
     return LIB_PATH
 
 
+def build_io(force=False, verbose=False):
+    """Compile the host-side ingestion library (include/ltr_io.h) with g++.  Returns its path."""
+    stale = (not os.path.exists(IO_LIB_PATH)
+             or any(os.path.getmtime(d) > os.path.getmtime(IO_LIB_PATH) for d in IO_DEPENDS))
+    if force or stale:
+        cmd = [os.environ.get("CXX", "g++"), "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
+               "-Wall", "-I", os.path.join(_ROOT, "include"), "-o", IO_LIB_PATH] + IO_SOURCES
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return IO_LIB_PATH
+
+
 if __name__ == "__main__":
     path = build_extension(force="--force" in sys.argv, verbose=True)
     print("built", path)
+    print("built", build_io(force="--force" in sys.argv, verbose=True))
