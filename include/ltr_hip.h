@@ -205,6 +205,27 @@ int ltr_linear_reduce_f32(const float *partials, const float *grad_out, int B, i
 int ltr_linear_reduce_loss_f32(const float *partials, const float *grad_out, const float *loss,
                                int B, int F, float *dW, float *db, float *loss_sum, void *stream);
 
+/* --- fused ReLU-MLP scorer + loss + backward --------------------
+ * Replaces the user-side composition `loss_fn(model(xs), ys, n)` + `.backward()` with `model` the
+ * feed-forward network of the reference's guide (docs/source/getting-started.rst:40-50:
+ * Linear(F,H1) / ReLU / Linear(H1,H2) / ReLU / Linear(H2,1); training loop :70-101) by one MFMA
+ * kernel plus a small deterministic reduction.
+ *   X (B,L,F) fp32; W1 (H1,F), b1 (H1), W2 (H2,H1), b2 (H2), W3 (1,H2), b3 (1): torch.nn.Linear
+ *   layout; grad_out (B) weights of the per-query losses (NULL = 1/B, i.e. `.mean()`).
+ *   loss (B); scores_out (B,L) or NULL (written for documents < n[b] only);
+ *   grads: ltr_mlp_param_count(F,H1,H2) floats = [dW1 | db1 | dW2 | db2 | dW3 | db3], the gradient
+ *   of sum_b grad_out[b] * loss[b];  loss_sum[0] = sum_b loss[b] or NULL.
+ * Shape limits of this kernel: L <= 128 (LTR_ERR_LIST_TOO_LONG), F % 4 == 0, F <= 224, H1 <= 64,
+ * H2 <= 16 (LTR_ERR_SHAPE).  workspace: ltr_mlp_workspace_bytes(B,F,H1,H2) bytes. */
+size_t ltr_mlp_param_count(int F, int H1, int H2);
+size_t ltr_mlp_workspace_bytes(int B, int F, int H1, int H2);
+int ltr_mlp_pairwise_f32(int kind, float sigma, const float *X, const float *W1, const float *b1,
+                         const float *W2, const float *b2, const float *W3, const float *b3,
+                         const void *rel, int rel_dtype, const int64_t *n, const float *grad_out,
+                         int B, int L, int F, int H1, int H2, float *loss, float *scores_out,
+                         float *grads, float *loss_sum, void *workspace, size_t workspace_bytes,
+                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -365,3 +365,85 @@ int oracle_linear_pairwise(int kind, double sigma, const double *X, const double
     free(scores); free(ds);
     return rc;
 }
+
+/* ---------------------------------------------------------------------------------------
+ * ReLU MLP scorer (F -> H1 -> H2 -> 1) + pairwise loss + backward: the documented training
+ * step `loss_fn(model(xs), ys, n)` weighted by gout[b], with `model` the feed-forward network
+ * of docs/source/getting-started.rst:40-50 (l1, relu, l2, relu, l3).  Weights in torch.nn.Linear
+ * layout: W1 (H1,F), W2 (H2,H1), W3 (1,H2).  grads = [dW1 | db1 | dW2 | db2 | dW3 | db3].
+ * relu'(0) = 0 as in torch.
+ * --------------------------------------------------------------------------------------- */
+int oracle_mlp_pairwise(int kind, double sigma, const double *X, const double *W1,
+                        const double *b1, const double *W2, const double *b2, const double *W3,
+                        double b3, const double *rel, const int64_t *n, const double *gout,
+                        int B, int L, int F, int H1, int H2, double *loss, double *scores_out,
+                        double *grads)
+{
+    const size_t R = (size_t)B * L;
+    double *scores = (double *)malloc(sizeof(double) * R);
+    double *ds = (double *)malloc(sizeof(double) * R);
+    double *h1 = (double *)malloc(sizeof(double) * (size_t)H1);
+    double *h2 = (double *)malloc(sizeof(double) * (size_t)H2);
+    double *d1 = (double *)malloc(sizeof(double) * (size_t)H1);
+    double *d2 = (double *)malloc(sizeof(double) * (size_t)H2);
+    if (!scores || !ds || !h1 || !h2 || !d1 || !d2) {
+        free(scores); free(ds); free(h1); free(h2); free(d1); free(d2);
+        return -2;
+    }
+    for (size_t r = 0; r < R; ++r) {
+        const double *x = X + r * F;
+        for (int j = 0; j < H1; ++j) {
+            double a = b1[j];
+            for (int f = 0; f < F; ++f) a += W1[(size_t)j * F + f] * x[f];
+            h1[j] = a > 0.0 ? a : 0.0;
+        }
+        double s = b3;
+        for (int k = 0; k < H2; ++k) {
+            double a = b2[k];
+            for (int j = 0; j < H1; ++j) a += W2[(size_t)k * H1 + j] * h1[j];
+            s += W3[k] * (a > 0.0 ? a : 0.0);
+        }
+        scores[r] = s;
+    }
+    int rc = oracle_pairwise_loss(kind, sigma, scores, rel, n, B, L, loss, ds);
+    if (rc == 0) {
+        double *dW1 = grads, *db1 = dW1 + (size_t)H1 * F, *dW2 = db1 + H1;
+        double *db2 = dW2 + (size_t)H2 * H1, *dW3 = db2 + H2, *db3 = dW3 + H2;
+        const size_t P = (size_t)H1 * F + H1 + (size_t)H2 * H1 + 2 * (size_t)H2 + 1;
+        for (size_t i = 0; i < P; ++i) grads[i] = 0.0;
+        for (int b = 0; b < B; ++b)
+            for (int l = 0; l < L; ++l) {
+                const size_t r = (size_t)b * L + l;
+                const double gr = gout[b] * ds[r];
+                if (gr == 0.0) continue;
+                const double *x = X + r * F;
+                for (int j = 0; j < H1; ++j) {              /* recompute the activations */
+                    double a = b1[j];
+                    for (int f = 0; f < F; ++f) a += W1[(size_t)j * F + f] * x[f];
+                    h1[j] = a > 0.0 ? a : 0.0;
+                    d1[j] = 0.0;
+                }
+                *db3 += gr;
+                for (int k = 0; k < H2; ++k) {
+                    double a = b2[k];
+                    for (int j = 0; j < H1; ++j) a += W2[(size_t)k * H1 + j] * h1[j];
+                    h2[k] = a > 0.0 ? a : 0.0;
+                    dW3[k] += gr * h2[k];
+                    d2[k] = (a > 0.0) ? gr * W3[k] : 0.0;
+                    db2[k] += d2[k];
+                    for (int j = 0; j < H1; ++j) {
+                        dW2[(size_t)k * H1 + j] += d2[k] * h1[j];
+                        d1[j] += d2[k] * W2[(size_t)k * H1 + j];
+                    }
+                }
+                for (int j = 0; j < H1; ++j) {
+                    if (!(h1[j] > 0.0)) continue;
+                    db1[j] += d1[j];
+                    for (int f = 0; f < F; ++f) dW1[(size_t)j * F + f] += d1[j] * x[f];
+                }
+            }
+        if (scores_out) memcpy(scores_out, scores, sizeof(double) * R);
+    }
+    free(scores); free(ds); free(h1); free(h2); free(d1); free(d2);
+    return rc;
+}

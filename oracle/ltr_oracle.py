@@ -144,6 +144,39 @@ def batch_pairs(x):
     return out
 
 
+def mlp_pairwise(kind, X, params, relevance, n, grad_out, sigma=1.0):
+    """ReLU MLP (F-H1-H2-1) scorer + loss + backward.  params = (W1, b1, W2, b2, W3, b3) in
+    torch.nn.Linear layout.  Returns (loss[B], scores[B,L], grads dict with the same keys)."""
+    Xd = _d(X)
+    B, L, F = Xd.shape
+    W1, b1, W2, b2, W3, b3 = [_d(a) for a in params]
+    H1, H2 = W1.shape[0], W2.shape[0]
+    assert W1.shape == (H1, F) and W2.shape == (H2, H1) and W3.size == H2 and b3.size == 1
+    y = _bl(relevance)
+    nn = _n(n)
+    go = _d(grad_out).reshape(B)
+    loss = np.zeros(B, dtype=np.float64)
+    scores = np.zeros((B, L), dtype=np.float64)
+    P = H1 * F + H1 + H2 * H1 + 2 * H2 + 1
+    grads = np.zeros(P, dtype=np.float64)
+    fn = _load().oracle_mlp_pairwise
+    fn.restype = ctypes.c_int
+    rc = fn(ctypes.c_int(KINDS[kind]), ctypes.c_double(sigma), _p(Xd), _p(W1), _p(b1.reshape(-1)),
+            _p(W2), _p(b2.reshape(-1)), _p(W3.reshape(-1)), ctypes.c_double(float(b3.reshape(-1)[0])),
+            _p(y), _p(nn, ctypes.c_int64), _p(go), B, L, F, H1, H2, _p(loss), _p(scores), _p(grads))
+    if rc != 0:
+        raise RuntimeError("oracle_mlp_pairwise failed: %d" % rc)
+    o = 0
+    out = {}
+    for key, shape in (("W1", (H1, F)), ("b1", (H1,)), ("W2", (H2, H1)), ("b2", (H2,)),
+                       ("W3", (1, H2)), ("b3", (1,))):
+        size = int(np.prod(shape))
+        out[key] = grads[o:o + size].reshape(shape).copy()
+        o += size
+    out["flat"] = grads
+    return loss, scores, out
+
+
 def linear_pairwise(kind, X, W, bias, relevance, n, grad_out, sigma=1.0):
     """Linear(F,1) scorer + loss: returns (loss[B], scores[B,L], dW[F], db)."""
     Xd = _d(X)

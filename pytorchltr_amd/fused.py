@@ -147,3 +147,167 @@ def linear_loss_step(xs, weight, bias, relevance, n, loss="hinge", grad_out=None
     if return_loss_sum:
         out = out + (lsum,)
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# ReLU MLP scorer (the network of the reference's guide) fused with the loss -- SURVEY.md 8 f-2
+# ---------------------------------------------------------------------------------------------
+MLP_MAX_LIST_LEN = 128
+MLP_MAX_FEATURES = 224
+MLP_MAX_HIDDEN = (64, 16)
+
+
+def mlp_supported(L, F, H1, H2):
+    """Shapes the fused MLP kernel takes (see include/ltr_hip.h: ltr_mlp_pairwise_f32)."""
+    return (0 < L <= MLP_MAX_LIST_LEN and 0 < F <= MLP_MAX_FEATURES and F % 4 == 0
+            and 0 < H1 <= MLP_MAX_HIDDEN[0] and 0 < H2 <= MLP_MAX_HIDDEN[1])
+
+
+def _flat_params(params, F):
+    W1, b1, W2, b2, W3, b3 = [t.detach().float().contiguous() for t in params]
+    H1, H2 = W1.shape[0], W2.shape[0]
+    if W1.shape != (H1, F) or b1.numel() != H1 or W2.shape != (H2, H1) or b2.numel() != H2 \
+            or W3.numel() != H2 or b3.numel() != 1:
+        raise ValueError("parameters must be those of Linear(F,H1), Linear(H1,H2), Linear(H2,1)")
+    return (W1, b1, W2, b2, W3, b3), H1, H2
+
+
+def _split_grads(flat, F, H1, H2):
+    sizes = (H1 * F, H1, H2 * H1, H2, H2, 1)
+    shapes = ((H1, F), (H1,), (H2, H1), (H2,), (1, H2), (1,))
+    out, o = [], 0
+    for size, shape in zip(sizes, shapes):
+        out.append(flat[o:o + size].view(shape))
+        o += size
+    return tuple(out)
+
+
+def mlp_loss_step(xs, params, relevance, n, loss="hinge", grad_out=None, return_scores=False,
+                  return_loss_sum=False, out=None):
+    """One fused forward+backward step of ``loss_fn(mlp(xs), relevance, n)`` without autograd.
+
+    Args:
+        xs: (B, L, F) float32 features on the device.
+        params: ``(W1, b1, W2, b2, W3, b3)`` of ``Linear(F,H1) / ReLU / Linear(H1,H2) / ReLU /
+            Linear(H2,1)`` in torch layout.
+        grad_out: (B,) weights of the per-query losses; None = 1/B (the ``.mean()`` of the guide's
+            training loop, docs/source/getting-started.rst:95).
+        out: optional preallocated flat gradient buffer of ``ltr_mlp_param_count`` floats.
+
+    Returns:
+        ``(loss[B], grads)`` with ``grads = (dW1, db1, dW2, db2, dW3, db3)`` views of one flat
+        buffer (available as ``grads[0].base`` / the ``out`` argument), then optionally the scores
+        (valid for documents < n only) and ``loss_sum`` (1,).
+    """
+    kind, sigma = _resolve_loss(loss)
+    X = _prepare_features(xs)
+    B, L, F = X.shape
+    flat_params, H1, H2 = _flat_params(params, F)
+    if not mlp_supported(L, F, H1, H2):
+        raise ValueError("fused MLP kernel takes L <= %d, F <= %d with F %% 4 == 0, hidden <= %s; "
+                         "got L=%d F=%d hidden=(%d, %d)" % (MLP_MAX_LIST_LEN, MLP_MAX_FEATURES,
+                                                            MLP_MAX_HIDDEN, L, F, H1, H2))
+    r = prepare_relevance(relevance, X[:, :, 0])
+    nn = prepare_n(n, B)
+    lib = _C.lib()
+    P = lib.ltr_mlp_param_count(F, H1, H2)
+    lossv = torch.empty(B, dtype=torch.float32, device=X.device)
+    flat = out if out is not None else torch.empty(P, dtype=torch.float32, device=X.device)
+    if flat.numel() != P or flat.dtype != torch.float32 or not flat.is_contiguous():
+        raise ValueError("out must be a contiguous float32 tensor of %d elements" % P)
+    lsum = torch.zeros(1, dtype=torch.float32, device=X.device) if return_loss_sum else None
+    scores = torch.zeros(B, L, dtype=torch.float32, device=X.device) if return_scores else None
+    ws_bytes = lib.ltr_mlp_workspace_bytes(B, F, H1, H2)
+    ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=X.device)
+    go = None if grad_out is None else grad_out.reshape(B).float().contiguous()
+    with _C.device_ctx(X):
+        _C.check(lib.ltr_mlp_pairwise_f32(
+            kind, float(sigma), _C.ptr(X), *[_C.ptr(t) for t in flat_params], _C.ptr(r),
+            _C.label_dtype(r), _C.ptr(nn), _C.ptr(go), B, L, F, H1, H2, _C.ptr(lossv),
+            _C.ptr(scores), _C.ptr(flat), _C.ptr(lsum), _C.ptr(ws), ws_bytes, _C.stream_of(X)))
+    res = (lossv, _split_grads(flat, F, H1, H2))
+    if return_scores:
+        res = res + (scores,)
+    if return_loss_sum:
+        res = res + (lsum,)
+    return res
+
+
+class _MLPLossFunction(torch.autograd.Function):
+    """Reduced (mean / sum) loss of the fused MLP step; the kernel already produced the parameter
+    gradients of the reduced loss, backward only scales them by the incoming scalar."""
+
+    @staticmethod
+    def forward(ctx, xs, relevance, n, kind_sigma, mean, *params):
+        B = xs.shape[0]
+        go = None if mean else torch.ones(B, dtype=torch.float32, device=xs.device)
+        loss = _KindProxy(*kind_sigma)
+        lossv, grads, lsum = mlp_loss_step(xs, params, relevance, n, loss=loss, grad_out=go,
+                                           return_loss_sum=True)
+        ctx.save_for_backward(*grads)
+        ctx.shapes = [p.shape for p in params]
+        ctx.per_query = lossv
+        total = lsum.reshape(())
+        out = total / B if (mean and B > 0) else total
+        ctx.mark_non_differentiable(lossv)
+        return out, lossv
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_total, grad_unused):
+        grads = ctx.saved_tensors
+        scaled = tuple((g * grad_total).reshape(s) for g, s in zip(grads, ctx.shapes))
+        return (None, None, None, None, None) + scaled
+
+
+class _KindProxy:
+    def __init__(self, kind, sigma):
+        self._kind = kind
+        self.sigma = sigma
+
+
+class FusedMLPLoss(torch.nn.Module):
+    """The guide's scorer and loss as one module: ``l1``/``l2``/``l3`` are ordinary
+    ``torch.nn.Linear`` layers (state_dict-compatible with the ``Model`` class of
+    docs/source/getting-started.rst:40-50), and ``forward(xs, relevance, n)`` returns the
+    *reduced* loss ``loss_fn(model(xs), relevance, n).mean()`` (or ``.sum()``) whose backward
+    fills the six parameter gradients -- computed by one fused MFMA kernel.
+
+    Shapes the kernel does not take (lists longer than 128, more than 224 features, ...) run as
+    the unfused composition: rocBLAS layers + the HIP loss kernel.  ``score(xs)`` evaluates the
+    network alone (for the metrics).
+    """
+
+    def __init__(self, in_features, loss="hinge", hidden=(50, 10), reduction="mean"):
+        super().__init__()
+        if reduction not in ("mean", "sum"):
+            raise ValueError("reduction must be 'mean' or 'sum'")
+        self.in_features = in_features
+        self.reduction = reduction
+        self.kind, self.sigma = _resolve_loss(loss)
+        self.l1 = torch.nn.Linear(in_features, hidden[0])
+        self.l2 = torch.nn.Linear(hidden[0], hidden[1])
+        self.l3 = torch.nn.Linear(hidden[1], 1)
+        self.last_losses = None
+
+    def score(self, xs):
+        o1 = torch.nn.functional.relu(self.l1(xs))
+        o2 = torch.nn.functional.relu(self.l2(o1))
+        return self.l3(o2)
+
+    def _params(self):
+        return (self.l1.weight, self.l1.bias, self.l2.weight, self.l2.bias, self.l3.weight,
+                self.l3.bias)
+
+    def forward(self, xs, relevance, n):
+        _C.require_device(xs, "xs")
+        B, L, F = xs.shape
+        if mlp_supported(L, F, self.l1.out_features, self.l2.out_features):
+            total, per_query = _MLPLossFunction.apply(
+                xs, relevance, n, (self.kind, self.sigma), self.reduction == "mean", *self._params())
+            self.last_losses = per_query
+            return total
+        from ._autograd import PairwiseLossFunction
+        per_query = PairwiseLossFunction.apply(self.score(xs), relevance, n, self.kind, self.sigma)
+        self.last_losses = per_query.detach()
+        return per_query.mean() if self.reduction == "mean" else per_query.sum()
