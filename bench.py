@@ -144,6 +144,65 @@ def try_graph(step, warm=3):
         return None
 
 
+def mlp_extra(kind, X, relevance, n, no_graph):
+    """the guide's 136-50-10-1 ReLU MLP + loss + backward as one fused MFMA step
+    (ltr_mlp_pairwise_f32), next to the same step written with torch layers + the HIP loss module."""
+    from pytorchltr_amd import _C, fused
+    from pytorchltr_amd import loss as L_
+    B, L, F = X.shape
+    H1, H2 = 50, 10
+    if not fused.mlp_supported(L, F, H1, H2):
+        return None
+    dev = X.device
+    torch.manual_seed(0)
+    m = fused.FusedMLPLoss(F, kind, hidden=(H1, H2)).to(dev)
+    lib = _C.lib()
+    P = lib.ltr_mlp_param_count(F, H1, H2)
+    ws_bytes = lib.ltr_mlp_workspace_bytes(B, F, H1, H2)
+    ws = torch.empty(ws_bytes // 4, device=dev)
+    grads = torch.empty(P, device=dev)
+    lossv = torch.empty(B, device=dev)
+    lsum = torch.zeros(1, device=dev)
+    params = [p.detach().contiguous() for p in (m.l1.weight, m.l1.bias, m.l2.weight, m.l2.bias,
+                                                m.l3.weight, m.l3.bias)]
+    kind_id = getattr(_C, kind.upper())
+
+    def launch():
+        _C.check(lib.ltr_mlp_pairwise_f32(
+            kind_id, 1.0, X.data_ptr(), *[p.data_ptr() for p in params], relevance.data_ptr(),
+            _C.LABEL_I64, n.data_ptr(), None, B, L, F, H1, H2, lossv.data_ptr(), None,
+            grads.data_ptr(), lsum.data_ptr(), ws.data_ptr(), ws_bytes,
+            torch.cuda.current_stream().cuda_stream))
+
+    for _ in range(5):
+        launch()
+    us, graphed = time_launches(launch, per_graph=10, replays=10)
+    docs = int(n.clamp(max=L).sum())
+    flops_per_doc = 2 * (F * H1 + H1 * H2 + H2) + 2 * (F * H1 + 2 * H1 * H2 + H2)   # fwd + bwd, no dX
+    out = {"step": "MLP %d-%d-%d-1 + %s fwd+bwd (2 launches: mlp_pairwise_kernel + mlp_reduce_kernel)" % (F, H1, H2, kind),
+           "us_per_step": us, "queries_per_s": B / (us * 1e-6),
+           "useful_TFLOPs": docs * flops_per_doc / (us * 1e-6) / 1e12,
+           "f32_mfma_peak_TFLOPs": 157.3,
+           "frac_of_f32_mfma_peak": docs * flops_per_doc / (us * 1e-6) / 1e12 / 157.3}
+    loss_fn = {"hinge": L_.PairwiseHingeLoss, "dcg_hinge": L_.PairwiseDCGHingeLoss,
+               "logistic": L_.PairwiseLogisticLoss, "arp1": L_.LambdaARPLoss1, "arp2": L_.LambdaARPLoss2,
+               "ndcg1": L_.LambdaNDCGLoss1, "ndcg2": L_.LambdaNDCGLoss2}[kind]()
+    ps = list(m.parameters())
+
+    def unfused():
+        for p_ in ps:
+            p_.grad = None
+        loss_fn(m.score(X), relevance, n).mean().backward()
+    for _ in range(5):
+        unfused()
+    res = {"eager_us": time_wall(unfused, 50, lambda: None) / 50 * 1e6}
+    rp = None if no_graph else try_graph(unfused)
+    if rp is not None:
+        res["hipgraph_us"] = time_wall(rp, 100, lambda: None) / 100 * 1e6
+    out["unfused_torch_layers_plus_loss_module"] = res
+    return out
+
+
 def cpu_baseline(kind, B, L, F, reps=5):
     """The reference-equivalent CPU path (materialising torch port) on this box's cores."""
     from oracle import materialized_torch as M
@@ -379,6 +438,11 @@ def main():
                                 "algorithmic_bytes_per_launch": loss_bytes,
                                 "achieved_GBs": loss_bytes / (l_avg * 1e-6) / 1e9,
                                 "frac_of_hbm_peak": loss_bytes / (l_avg * 1e-6) / 1e9 / HBM_PEAK_GBS}
+
+        if n_gpus == 1:
+            mlp = mlp_extra(kind, X, relevance, n, args.no_graph)
+            if mlp is not None:
+                extra["mlp_scorer_fused"] = mlp
 
         cpu = None
         if n_gpus == 1 and not args.no_cpu_baseline:

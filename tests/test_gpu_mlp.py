@@ -191,3 +191,28 @@ def test_argument_errors():
                                     z, None, z, 4, None) == -5              # LTR_ERR_WORKSPACE
     assert lib.ltr_mlp_pairwise_f32(9, 1.0, z, z, z, z, z, z, z, z, 0, z, None, 1, 16, 8, 4, 4, z, None,
                                     z, None, z, 1 << 30, None) == -3        # LTR_ERR_KIND
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_against_reference_fp32_outputs(kind):
+    """The kernel vs what the REAL reference computed in float32 for the guide's network
+    (tests/golden/mlp_vectors.npz): same tolerance class as fp32-vs-fp32 round-off."""
+    import os
+    from pytorchltr_amd import fused
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mlp_vectors.npz"))
+    tag = "f32_guide"
+    dev = torch.device("cuda")
+    names = ("l1.weight", "l1.bias", "l2.weight", "l2.bias", "l3.weight", "l3.bias")
+    X = torch.from_numpy(z[tag + "/X"]).to(dev)
+    y = torch.from_numpy(z[tag + "/y"]).to(dev)
+    n = torch.from_numpy(z[tag + "/n"]).to(dev)
+    params = [torch.from_numpy(z["%s/param/%s" % (tag, k)]).to(dev) for k in names]
+    lossv, grads, scores = fused.mlp_loss_step(X, params, y, n, loss=kind, return_scores=True)
+    B, L = scores.shape
+    valid = (np.arange(L)[None, :] < z[tag + "/n"][:, None])
+    assert np.allclose(scores.cpu().numpy()[valid], z["%s/%s/scores" % (tag, kind)][valid], rtol=1e-5, atol=2e-6)
+    assert np.allclose(lossv.cpu().numpy(), z["%s/%s/loss" % (tag, kind)], rtol=3e-5, atol=1e-5)
+    scale = max(np.abs(z["%s/%s/grad/%s" % (tag, kind, k)]).max() for k in names)
+    for got, name in zip(grads, names):
+        want = z["%s/%s/grad/%s" % (tag, kind, name)]
+        assert np.abs(got.cpu().numpy().reshape(want.shape) - want).max() <= 5e-5 * scale + 1e-6, (kind, name)

@@ -203,3 +203,55 @@ def test_oracle_vs_python_rederivation_and_finite_differences(kind, name):
 def test_oracle_rejects_bad_kind():
     lib = O._load()
     assert lib.oracle_pairwise_loss(99, 0, None, None, None, 0, 0, None, None) == -1
+
+
+# ---- MLP scorer + loss step ---------------------------------------------------
+
+_MLP_KINDS = ("hinge", "dcg_hinge", "logistic", "arp1", "arp2", "ndcg1", "ndcg2")
+
+
+def _mlp_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mlp_vectors.npz"))
+
+
+@pytest.mark.parametrize("kind", _MLP_KINDS)
+def test_mlp_oracle_matches_reference_autograd(kind):
+    """oracle_mlp_pairwise vs the real reference: torch layers + the reference's loss modules +
+    .mean().backward(), float64 (tests/golden/generate_mlp_golden.py)."""
+    from oracle import ltr_oracle as O
+    z = _mlp_golden()
+    tag = "f64_small"
+    X, y, n = z[tag + "/X"], z[tag + "/y"], z[tag + "/n"]
+    names = ("l1.weight", "l1.bias", "l2.weight", "l2.bias", "l3.weight", "l3.bias")
+    params = [z["%s/param/%s" % (tag, k)] for k in names]
+    B = X.shape[0]
+    loss, scores, grads = O.mlp_pairwise(kind, X, params, y, n, np.full(B, 1.0 / B))
+    # the NDCG losses keep fp32 discount tables in the reference even for fp64 inputs
+    rel = 3e-7 if kind in ("ndcg1", "ndcg2") else 1e-12
+    assert np.allclose(scores, z["%s/%s/scores" % (tag, kind)], rtol=1e-13, atol=1e-13)
+    assert np.allclose(loss, z["%s/%s/loss" % (tag, kind)], rtol=rel, atol=1e-13)
+    scale = max(np.abs(z["%s/%s/grad/%s" % (tag, kind, k)]).max() for k in names)
+    for key, name in zip(("W1", "b1", "W2", "b2", "W3", "b3"), names):
+        want = z["%s/%s/grad/%s" % (tag, kind, name)]
+        assert np.abs(grads[key].reshape(want.shape) - want).max() <= rel * scale + 1e-15, (kind, name)
+
+
+@pytest.mark.parametrize("kind", _MLP_KINDS)
+def test_mlp_oracle_matches_reference_fp32_guide_network(kind):
+    """The guide's 136-50-10-1 network run by the reference in float32: the fp64 oracle agrees
+    to fp32 round-off."""
+    from oracle import ltr_oracle as O
+    z = _mlp_golden()
+    tag = "f32_guide"
+    X, y, n = z[tag + "/X"], z[tag + "/y"], z[tag + "/n"]
+    names = ("l1.weight", "l1.bias", "l2.weight", "l2.bias", "l3.weight", "l3.bias")
+    params = [z["%s/param/%s" % (tag, k)] for k in names]
+    B = X.shape[0]
+    loss, scores, grads = O.mlp_pairwise(kind, X, params, y, n, np.full(B, 1.0 / B))
+    assert np.allclose(scores, z["%s/%s/scores" % (tag, kind)], rtol=1e-5, atol=2e-6)
+    assert np.allclose(loss, z["%s/%s/loss" % (tag, kind)], rtol=2e-5, atol=1e-5)
+    scale = max(np.abs(z["%s/%s/grad/%s" % (tag, kind, k)]).max() for k in names)
+    for key, name in zip(("W1", "b1", "W2", "b2", "W3", "b3"), names):
+        want = z["%s/%s/grad/%s" % (tag, kind, name)]
+        assert np.abs(grads[key].reshape(want.shape) - want).max() <= 3e-5 * scale + 1e-6, (kind, name)
