@@ -159,9 +159,12 @@ def test_module_matches_unfused_composition(reduction):
     (ref * 3.0).backward()
     assert torch.allclose(out, ref, rtol=1e-5, atol=1e-6)
     assert torch.allclose(fusedm.last_losses, per_query.detach(), rtol=1e-5, atol=1e-5)
+    # absolute tolerance from the scale of the whole gradient: d/d(l3.bias) = sum of ds is a
+    # cancelling sum whose exact value is 0
+    scale = max(float(b.grad.abs().max()) for b in plain.parameters())
     for a, b in zip(fusedm.parameters(), plain.parameters()):
         assert a.grad is not None
-        assert torch.allclose(a.grad, b.grad, rtol=2e-4, atol=1e-5 * max(1.0, float(b.grad.abs().max())))
+        assert torch.allclose(a.grad, b.grad, rtol=2e-4, atol=2e-5 * max(1.0, scale))
 
 
 def test_module_long_lists_take_the_unfused_path():
