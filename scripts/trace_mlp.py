@@ -15,7 +15,8 @@ import bench  # noqa: E402
 from pytorchltr_amd import _C  # noqa: E402
 
 PHASES = ["weights->LDS", "labels", "layer1 MFMA", "layers 2,3 + barrier", "pair pass", "dH2/dW2/dH1",
-          "dH1->LDS", "dW1 MFMA", "fold", "write partial"]
+          "dH1->LDS", "dW1 MFMA", "fold", "write partial", "(sched) n loaded", "(sched) vote+hist",
+          "(sched) prefix", "(sched) rank"]
 
 
 def main():
@@ -51,7 +52,7 @@ def main():
         assert rc == 0, rc
         torch.cuda.synchronize()
     t = trace.view(grid, 16).double().cpu()
-    tot = t[:, :10].sum(1)
+    tot = t[:, :14].sum(1)
     print("workgroups %d, queries/workgroup %.1f; total cycles/workgroup mean %.0f max %.0f" % (
         grid, B / grid, tot.mean(), tot.max()))
     for i, name in enumerate(PHASES):
