@@ -756,10 +756,101 @@ struct MetricParams {
     int msplit;
 };
 
+// ---------------------------------------------------------------------------------
+// Ranks of long lists by a bitonic sort instead of the O(n^2) counting rank.
+// Every document becomes one 64-bit key: (order-reversed score bits << 32) | index, so that an
+// ascending unsigned sort is exactly "score descending, index ascending" -- the tie rule of the
+// counting rank (-0.0 is folded into +0.0 first so that it ties with it, as the float compare
+// does).  Slots past n hold the all-ones sentinel and stay at the tail.  Element i = e*T + tid
+// lives in register e of thread tid; a compare-exchange partner at distance j is in the same
+// thread (j >= T), reached through LDS (64 <= j < T, one buffer, two barriers), or a lane
+// shuffle (j < 64).  P = E*T is a power of two >= n.  O(P log^2 P) work: L = 1000 ranks in
+// ~1/7 of the counting rank's time on MI355X.  NaN scores sort first (the counting rank gave
+// them colliding ranks).
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long rank_key(float v, int idx)
+{
+    const unsigned bits = __float_as_uint(v + 0.0f);
+    const unsigned asc = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+    return ((unsigned long long)(~asc) << 32) | (unsigned)idx;
+}
+
+template <int E>
+__device__ __forceinline__ void sort_ranks(unsigned long long (&v)[E], int P, int nb, int *rank_out,
+                                           unsigned long long *xbuf)
+{
+    const int tid = threadIdx.x;
+    const int T = blockDim.x;
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= T) {
+                const int je = j / T;                          // partner register
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if ((e & je) == 0 && (e | je) < E) {
+                        const int i = e * T + tid;
+                        const bool up = (i & k) == 0;
+                        const unsigned long long a = v[e], b = v[e | je];
+                        const bool swap = (a > b) == up;
+                        v[e] = swap ? b : a;
+                        v[e | je] = swap ? a : b;
+                    }
+                }
+            } else {
+                unsigned long long other[E];
+                if (j >= 64) {
+                    __syncthreads();                           // previous readers of xbuf are done
+#pragma unroll
+                    for (int e = 0; e < E; ++e) xbuf[e * T + tid] = v[e];
+                    __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < E; ++e) other[e] = xbuf[(e * T + tid) ^ j];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v[e], j);
+                        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v[e] >> 32), j);
+                        other[e] = ((unsigned long long)hi << 32) | lo;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = e * T + tid;
+                    const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
+                    const bool smaller = v[e] < other[e];
+                    v[e] = (smaller == keep_min) ? v[e] : other[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int idx = (int)(unsigned)v[e];
+        if (v[e] != ~0ull && idx < nb) rank_out[idx] = e * T + tid;
+    }
+}
+
 __host__ __device__ inline size_t metric_lds_bytes(int L)
 {
     const size_t L4 = (size_t)((L + 3) & ~3);
     return 8 * L4 + 8 * L4 + 8 * L4 + 32 * 4 + 64 * 4;   // sy, ranks, two curves, red, scan
+}
+
+// lists longer than this take the sort path (DPT == 0 instantiation of metric_kernel)
+#ifndef LTR_SORT_RANK_MIN
+#define LTR_SORT_RANK_MIN 128
+#endif
+constexpr int kSortRankMinLen = LTR_SORT_RANK_MIN;
+__host__ __device__ inline int sort_pow2(int L)
+{
+    int P = 64;
+    while (P < L) P <<= 1;
+    return P;
+}
+__host__ __device__ inline size_t metric_lds_bytes_sort(int L)
+{
+    const size_t L4 = (size_t)((L + 3) & ~3);
+    return 8 * L4 + 8 * L4 + 8 * (size_t)sort_pow2(L) + 32 * 4 + 64 * 4;
 }
 
 // Inclusive prefix sum of buf[0..L) in place (LDS).  Thread t owns a contiguous chunk.
@@ -829,10 +920,33 @@ metric_kernel(MetricParams p)
     const int m0 = __builtin_amdgcn_readfirstlane(slice * mlen);
     const int m1 = __builtin_amdgcn_readfirstlane(min(nb, m0 + mlen));
     const bool with_y = (OP == METRIC_DCG) && p.normalize;
-    if (with_y)
-        count_ranks<DPT, true>(sy, nb, owners, o, m0, m1, msplit > 1, rank_s, rank_y);
+    if (DPT <= 0) {
+        // long lists: bitonic sort of (score, index) keys -- and of (label, index) for the ideal
+        // ranking -- through the curve buffer; T = min(1024, P), E = P / T registers per thread
+        // (DPT = 0, -2, -4 stands for E = 1, 2, 4)
+        constexpr int E = DPT == 0 ? 1 : (DPT == -2 ? 2 : 4);
+        unsigned long long *xbuf = reinterpret_cast<unsigned long long *>(curve);
+        int Pq = 64;                                    // smallest power of two >= n of this query
+        while (Pq < nb) Pq <<= 1;
+        unsigned long long v[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = e * T + tid;
+            v[e] = (i < nb) ? rank_key(sy[i].x, i) : ~0ull;
+        }
+        sort_ranks<E>(v, Pq, nb, rank_s, xbuf);
+        if (with_y) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = e * T + tid;
+                v[e] = (i < nb) ? rank_key(sy[i].y, i) : ~0ull;
+            }
+            sort_ranks<E>(v, Pq, nb, rank_y, xbuf);
+        }
+    } else if (with_y)
+        count_ranks<(DPT > 0 ? DPT : 1), true>(sy, nb, owners, o, m0, m1, msplit > 1, rank_s, rank_y);
     else
-        count_ranks<DPT, false>(sy, nb, owners, o, m0, m1, msplit > 1, rank_s, rank_y);
+        count_ranks<(DPT > 0 ? DPT : 1), false>(sy, nb, owners, o, m0, m1, msplit > 1, rank_s, rank_y);
     __syncthreads();
 
     if (OP == METRIC_RANK) {
@@ -1160,6 +1274,26 @@ template <int OP>
 int launch_metric(const MetricParams &p0, hipStream_t stream)
 {
     MetricParams p = p0;
+#ifndef LTR_NO_SORT_RANK
+    if (p.L > kSortRankMinLen) {
+        const int P = sort_pow2(p.L);
+        const int T = P < 1024 ? P : 1024;              // E = P / T <= 4 registers per thread
+        p.msplit = 1;
+        const size_t lds = metric_lds_bytes_sort(p.L);
+        const dim3 sgrid((unsigned)p.B), sblock((unsigned)T);
+        if (P <= 1024) {
+            LTR_ENSURE_LDS((metric_kernel<OP, 0>), lds);
+            hipLaunchKernelGGL((metric_kernel<OP, 0>), sgrid, sblock, lds, stream, p);
+        } else if (P == 2048) {
+            LTR_ENSURE_LDS((metric_kernel<OP, -2>), lds);
+            hipLaunchKernelGGL((metric_kernel<OP, -2>), sgrid, sblock, lds, stream, p);
+        } else {
+            LTR_ENSURE_LDS((metric_kernel<OP, -4>), lds);
+            hipLaunchKernelGGL((metric_kernel<OP, -4>), sgrid, sblock, lds, stream, p);
+        }
+        return (int)hipGetLastError();
+    }
+#endif
     LaunchShape s = choose_shape(p.B, p.L);
     p.msplit = s.msplit;
     const dim3 grid((unsigned)p.B), block((unsigned)(s.owners * s.msplit));

@@ -120,3 +120,31 @@ def test_extreme_n_values_and_nonfinite_padding():
         for other in (s4, s5):
             got = _run_direct(kind, other.numpy(), y3.numpy(), n3.numpy())
             assert np.array_equal(base[0], got[0]) and np.array_equal(base[1], got[1]), kind
+
+
+@pytest.mark.parametrize("L", [129, 200, 256, 300, 512, 1000, 1024, 1500, 2048, 2049, 4096])
+def test_sorted_ranks_with_ties_on_long_lists(L):
+    """Lists longer than 128 are ranked by a bitonic sort of (score, index) keys.  The tie rule
+    must be the counting rank's: score descending, then index ascending, padded tail in index
+    order -- bit-exact against the oracle on rows that are FULL of ties (few distinct scores,
+    all-equal rows, +0.0 / -0.0, -inf scores), and the metrics built on the ranks agree."""
+    from pytorchltr_amd.evaluation import arp, ndcg
+    from pytorchltr_amd.utils import rank_by_score
+    dev = torch.device("cuda")
+    B = 7
+    g = torch.Generator().manual_seed(L)
+    scores = torch.randint(-3, 4, (B, L), generator=g).float() * 0.5       # 7 distinct values
+    scores[1] = 1.25                                                        # one value only
+    scores[2, ::2] = 0.0
+    scores[2, 1::2] = -0.0                                                  # signed zeros tie
+    scores[3] = torch.randn(L, generator=g)
+    scores[3, ::5] = float("-inf")
+    y = torch.randint(0, 5, (B, L), generator=g)
+    n = torch.tensor([L, L, L - 1, L // 2 + 1, 1, 0, L + 3])
+    got = rank_by_score(scores.to(dev), n.to(dev)).cpu().numpy()
+    want = O.rank_by_score(scores.numpy(), n.numpy())
+    assert np.array_equal(got, want)
+    y0 = y * (torch.arange(L)[None, :] < n[:, None])
+    for fn, ofn in ((lambda: ndcg(scores.to(dev), y0.to(dev), n.to(dev), k=10), lambda: O.ndcg(scores.numpy(), y0.numpy(), n.numpy(), k=10)),
+                    (lambda: arp(scores.to(dev), y0.to(dev), n.to(dev)), lambda: O.arp(scores.numpy(), y0.numpy(), n.numpy()))):
+        assert np.allclose(fn().cpu().numpy(), ofn(), rtol=2e-5, atol=1e-6)
