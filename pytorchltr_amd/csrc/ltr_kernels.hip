@@ -256,6 +256,92 @@ __device__ __forceinline__ void pair_rowweight(float sk, float ak, float sm, flo
     g += am - (ak + am) * sneg;                        // -a_k sig(-x) + a_m sig(x)
 }
 
+// lists longer than this take the sort path (DPT == 0 instantiation of metric_kernel)
+#ifndef LTR_SORT_RANK_MIN
+#define LTR_SORT_RANK_MIN 128
+#endif
+constexpr int kSortRankMinLen = LTR_SORT_RANK_MIN;
+__host__ __device__ inline int sort_pow2(int L)
+{
+    int P = 64;
+    while (P < L) P <<= 1;
+    return P;
+}
+
+// ---------------------------------------------------------------------------------
+// Ranks of long lists by a bitonic sort instead of the O(n^2) counting rank.
+// Every document becomes one 64-bit key: (order-reversed score bits << 32) | index, so that an
+// ascending unsigned sort is exactly "score descending, index ascending" -- the tie rule of the
+// counting rank (-0.0 is folded into +0.0 first so that it ties with it, as the float compare
+// does).  Slots past n hold the all-ones sentinel and stay at the tail.  Element i = e*T + tid
+// lives in register e of thread tid; a compare-exchange partner at distance j is in the same
+// thread (j >= T), reached through LDS (64 <= j < T, one buffer, two barriers), or a lane
+// shuffle (j < 64).  P = E*T is a power of two >= n.  O(P log^2 P) work: L = 1000 ranks in
+// ~1/7 of the counting rank's time on MI355X.  NaN scores sort first (the counting rank gave
+// them colliding ranks).
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long rank_key(float v, int idx)
+{
+    const unsigned bits = __float_as_uint(v + 0.0f);
+    const unsigned asc = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+    return ((unsigned long long)(~asc) << 32) | (unsigned)idx;
+}
+
+template <int E>
+__device__ __forceinline__ void sort_ranks(unsigned long long (&v)[E], int P, int nb, int *rank_out,
+                                           unsigned long long *xbuf)
+{
+    const int tid = threadIdx.x;
+    const int T = blockDim.x;
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= T) {
+                const int je = j / T;                          // partner register
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if ((e & je) == 0 && (e | je) < E) {
+                        const int i = e * T + tid;
+                        const bool up = (i & k) == 0;
+                        const unsigned long long a = v[e], b = v[e | je];
+                        const bool swap = (a > b) == up;
+                        v[e] = swap ? b : a;
+                        v[e | je] = swap ? a : b;
+                    }
+                }
+            } else {
+                unsigned long long other[E];
+                if (j >= 64) {
+                    __syncthreads();                           // previous readers of xbuf are done
+#pragma unroll
+                    for (int e = 0; e < E; ++e) xbuf[e * T + tid] = v[e];
+                    __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < E; ++e) other[e] = xbuf[(e * T + tid) ^ j];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v[e], j);
+                        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v[e] >> 32), j);
+                        other[e] = ((unsigned long long)hi << 32) | lo;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = e * T + tid;
+                    const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
+                    const bool smaller = v[e] < other[e];
+                    v[e] = (smaller == keep_min) ? v[e] : other[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int idx = (int)(unsigned)v[e];
+        if (v[e] != ~0ull && idx < nb) rank_out[idx] = e * T + tid;
+    }
+}
+
 struct LossParams {
     const float *scores;
     const void *rel;
@@ -293,6 +379,7 @@ struct QueryLds {
     int *rank_s;
     int *rank_y;
     float *red;
+    unsigned gbytes;      // bytes of the gpart region (the sort path borrows its tail)
 };
 
 template <int KIND>
@@ -315,6 +402,7 @@ __device__ __forceinline__ QueryLds carve_query_lds(unsigned char *base, int L4,
     size_t g = 4 * (size_t)L4 * msplit;
     if ((KIND == LTR_NDCG1 || KIND == LTR_NDCG2) && g < 8 * (size_t)L4) g = 8 * (size_t)L4;
     cur += g;
+    q.gbytes = (unsigned)g;
     q.red = reinterpret_cast<float *>(cur);
     return q;
 }
@@ -328,7 +416,36 @@ __device__ __forceinline__ void prepare_ndcg(const QueryLds &q, int nb, int owne
     const int tid = threadIdx.x;
     const int T = blockDim.x;
     float2 *sy = q.sy;
-    count_ranks<DPT, true>(sy, nb, owners, o, m0, m1, partial, q.rank_s, q.rank_y);
+    // Lists longer than kSortRankMinLen: both rankings by a bitonic sort of packed (key, index)
+    // words (see sort_ranks) when the exchange buffer fits behind the rank arrays in the gpart
+    // region -- it always does on the symmetric path (L <= 1024); otherwise the counting rank.
+    const int L4r = (int)(q.rank_y - q.rank_s);
+    int Pq = 64;
+    while (Pq < nb) Pq <<= 1;
+    // (every thread writes its register(s) to the exchange buffer: max(Pq, T) or 4T words)
+    const unsigned xwords = (unsigned)(Pq <= T ? T : 4 * T);
+    const bool sorted = nb > kSortRankMinLen && Pq <= 4 * T &&
+                        q.gbytes >= 8u * (unsigned)L4r + 8u * xwords;
+    if (sorted) {
+        unsigned long long *xbuf = reinterpret_cast<unsigned long long *>(q.rank_s + 2 * L4r);
+        if (Pq <= T) {
+            unsigned long long v[1];
+            v[0] = (tid < nb) ? rank_key(sy[tid].x, tid) : ~0ull;
+            sort_ranks<1>(v, Pq, nb, q.rank_s, xbuf);
+            v[0] = (tid < nb) ? rank_key(sy[tid].y, tid) : ~0ull;
+            sort_ranks<1>(v, Pq, nb, q.rank_y, xbuf);
+        } else {
+            unsigned long long v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (e * T + tid < nb) ? rank_key(sy[e * T + tid].x, e * T + tid) : ~0ull;
+            sort_ranks<4>(v, Pq, nb, q.rank_s, xbuf);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (e * T + tid < nb) ? rank_key(sy[e * T + tid].y, e * T + tid) : ~0ull;
+            sort_ranks<4>(v, Pq, nb, q.rank_y, xbuf);
+        }
+    } else {
+        count_ranks<DPT, true>(sy, nb, owners, o, m0, m1, partial, q.rank_s, q.rank_y);
+    }
     __syncthreads();
     // _max_dcg (loss/pairwise_lambda.py:231-241): labels sorted descending over the
     // first n documents, gains 2^y - 1, discounts log2(2 + r).
@@ -756,97 +873,12 @@ struct MetricParams {
     int msplit;
 };
 
-// ---------------------------------------------------------------------------------
-// Ranks of long lists by a bitonic sort instead of the O(n^2) counting rank.
-// Every document becomes one 64-bit key: (order-reversed score bits << 32) | index, so that an
-// ascending unsigned sort is exactly "score descending, index ascending" -- the tie rule of the
-// counting rank (-0.0 is folded into +0.0 first so that it ties with it, as the float compare
-// does).  Slots past n hold the all-ones sentinel and stay at the tail.  Element i = e*T + tid
-// lives in register e of thread tid; a compare-exchange partner at distance j is in the same
-// thread (j >= T), reached through LDS (64 <= j < T, one buffer, two barriers), or a lane
-// shuffle (j < 64).  P = E*T is a power of two >= n.  O(P log^2 P) work: L = 1000 ranks in
-// ~1/7 of the counting rank's time on MI355X.  NaN scores sort first (the counting rank gave
-// them colliding ranks).
-// ---------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long rank_key(float v, int idx)
-{
-    const unsigned bits = __float_as_uint(v + 0.0f);
-    const unsigned asc = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
-    return ((unsigned long long)(~asc) << 32) | (unsigned)idx;
-}
-
-template <int E>
-__device__ __forceinline__ void sort_ranks(unsigned long long (&v)[E], int P, int nb, int *rank_out,
-                                           unsigned long long *xbuf)
-{
-    const int tid = threadIdx.x;
-    const int T = blockDim.x;
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j >= T) {
-                const int je = j / T;                          // partner register
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    if ((e & je) == 0 && (e | je) < E) {
-                        const int i = e * T + tid;
-                        const bool up = (i & k) == 0;
-                        const unsigned long long a = v[e], b = v[e | je];
-                        const bool swap = (a > b) == up;
-                        v[e] = swap ? b : a;
-                        v[e | je] = swap ? a : b;
-                    }
-                }
-            } else {
-                unsigned long long other[E];
-                if (j >= 64) {
-                    __syncthreads();                           // previous readers of xbuf are done
-#pragma unroll
-                    for (int e = 0; e < E; ++e) xbuf[e * T + tid] = v[e];
-                    __syncthreads();
-#pragma unroll
-                    for (int e = 0; e < E; ++e) other[e] = xbuf[(e * T + tid) ^ j];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v[e], j);
-                        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v[e] >> 32), j);
-                        other[e] = ((unsigned long long)hi << 32) | lo;
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const int i = e * T + tid;
-                    const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
-                    const bool smaller = v[e] < other[e];
-                    v[e] = (smaller == keep_min) ? v[e] : other[e];
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int idx = (int)(unsigned)v[e];
-        if (v[e] != ~0ull && idx < nb) rank_out[idx] = e * T + tid;
-    }
-}
-
 __host__ __device__ inline size_t metric_lds_bytes(int L)
 {
     const size_t L4 = (size_t)((L + 3) & ~3);
     return 8 * L4 + 8 * L4 + 8 * L4 + 32 * 4 + 64 * 4;   // sy, ranks, two curves, red, scan
 }
 
-// lists longer than this take the sort path (DPT == 0 instantiation of metric_kernel)
-#ifndef LTR_SORT_RANK_MIN
-#define LTR_SORT_RANK_MIN 128
-#endif
-constexpr int kSortRankMinLen = LTR_SORT_RANK_MIN;
-__host__ __device__ inline int sort_pow2(int L)
-{
-    int P = 64;
-    while (P < L) P <<= 1;
-    return P;
-}
 __host__ __device__ inline size_t metric_lds_bytes_sort(int L)
 {
     const size_t L4 = (size_t)((L + 3) & ~3);
