@@ -259,6 +259,13 @@ def main():
     ap.add_argument("--full-lists", action="store_true", help="n == list_len for every query")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result: RCCL prints a version banner to stdout when
+    # a communicator is created, and other libraries may chat too -- send file descriptor 1 to
+    # stderr for the duration of the run and write the result to the saved descriptor at the end
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -279,7 +286,7 @@ def main():
         # capturing").  With a process group alive, launch eagerly -- the direct C-ABI step is
         # host-cheap (3 launches + 1 collective) and was as fast as graph replay at N=1.
         global GRAPHS_OK
-        GRAPHS_OK = False
+        GRAPHS_OK = os.environ.get("LTR_BENCH_DIST_GRAPH", "") in ("kernels", "all")   # experiments only
 
     def barrier():
         if dist is not None:
@@ -336,6 +343,18 @@ def main():
             modes["hipgraph"] = replay
     else:
         modes["eager"] = fwd_bwd_allreduce
+        dist_graph = os.environ.get("LTR_BENCH_DIST_GRAPH", "")
+        if dist_graph == "kernels":                 # graph of the two kernels + eager collective
+            replay = try_graph(fwd_bwd)
+            if replay is not None:
+                def graph_then_allreduce():
+                    replay()
+                    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                modes["hipgraph_kernels+eager_allreduce"] = graph_then_allreduce
+        elif dist_graph == "all":                   # the collective captured too
+            replay = try_graph(fwd_bwd_allreduce)
+            if replay is not None:
+                modes["hipgraph_with_allreduce"] = replay
     for name, fn in modes.items():
         for _ in range(args.warmup):
             fn()
@@ -464,8 +483,10 @@ def main():
     barrier()
     if dist is not None:
         dist.destroy_process_group()
+    sys.stdout.flush()
     if out is not None:
-        print(json.dumps(out))
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    os.close(result_fd)
 
 
 if __name__ == "__main__":
