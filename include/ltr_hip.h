@@ -88,6 +88,17 @@ int ltr_pairwise_loss_f32_cfg(int kind, float sigma, const float *scores, const 
                               int rel_dtype, const int64_t *n, int B, int L, float *loss,
                               float *dscores, int owners, int dpt, int msplit, void *stream);
 
+/* Same result as ltr_pairwise_loss_f32 for batches where one workgroup per query cannot balance
+ * the machine (lists longer than 256 on a batch of fewer than ~8 queries per CU, e.g. 256 x 1000):
+ * up to 8 workgroups share a query's pair work, a finish kernel adds their parts in a fixed order
+ * (deterministic).  workspace: ltr_pairwise_loss_workspace_bytes(kind, B, L) bytes (0 = the plain path
+ * is taken and workspace may be NULL).  Replaces the same reference symbols as
+ * ltr_pairwise_loss_f32. */
+size_t ltr_pairwise_loss_workspace_bytes(int kind, int B, int L);
+int ltr_pairwise_loss_ws_f32(int kind, float sigma, const float *scores, const void *rel,
+                             int rel_dtype, const int64_t *n, int B, int L, float *loss,
+                             float *dscores, void *workspace, size_t workspace_bytes, void *stream);
+
 /*
  * Backward of the reference's per-query output w.r.t. scores: out[b,j] = grad_out[b] *
  * dscores[b,j] (what autograd computes for `loss.mean().backward()`, with grad_out = 1/B).

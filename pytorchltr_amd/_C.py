@@ -25,6 +25,8 @@ SIGNATURES = {
     "ltr_max_list_len": (_i, []),
     "ltr_pairwise_loss_f32": (_i, [_i, _f, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "ltr_pairwise_loss_f32_cfg": (_i, [_i, _f, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
+    "ltr_pairwise_loss_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ltr_pairwise_loss_ws_f32": (_i, [_i, _f, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "ltr_scale_rows_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "ltr_pairwise_loss_f64": (_i, [_i, ctypes.c_double, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "ltr_scale_rows_f64": (_i, [_vp, _vp, _i, _i, _vp, _vp]),

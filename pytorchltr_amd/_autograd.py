@@ -19,10 +19,19 @@ class PairwiseLossFunction(torch.autograd.Function):
         loss = torch.empty(B, dtype=s.dtype, device=s.device)
         ds = torch.empty(B, L, dtype=s.dtype, device=s.device) if need_grad else None
         if B > 0:
-            entry = _C.lib().ltr_pairwise_loss_f64 if f64 else _C.lib().ltr_pairwise_loss_f32
+            lib = _C.lib()
             with _C.device_ctx(s):
-                _C.check(entry(kind, float(sigma), _C.ptr(s), _C.ptr(r), _C.label_dtype(r),
-                               _C.ptr(nn), B, L, _C.ptr(loss), _C.ptr(ds), _C.stream_of(s)))
+                # long lists on a small batch: several workgroups share a query (needs scratch)
+                ws_bytes = 0 if f64 else lib.ltr_pairwise_loss_workspace_bytes(kind, B, L)
+                if ws_bytes > 0:
+                    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=s.device)
+                    _C.check(lib.ltr_pairwise_loss_ws_f32(
+                        kind, float(sigma), _C.ptr(s), _C.ptr(r), _C.label_dtype(r), _C.ptr(nn), B, L,
+                        _C.ptr(loss), _C.ptr(ds), _C.ptr(ws), ws_bytes, _C.stream_of(s)))
+                else:
+                    entry = lib.ltr_pairwise_loss_f64 if f64 else lib.ltr_pairwise_loss_f32
+                    _C.check(entry(kind, float(sigma), _C.ptr(s), _C.ptr(r), _C.label_dtype(r),
+                                   _C.ptr(nn), B, L, _C.ptr(loss), _C.ptr(ds), _C.stream_of(s)))
         if need_grad:
             ctx.save_for_backward(ds)
         ctx.in_shape = scores.shape
@@ -53,14 +62,21 @@ def pairwise_loss(scores, relevance, n, kind, sigma=1.0):
 
 def pairwise_loss_and_grad(scores, relevance, n, kind, sigma=1.0, cfg=None):
     """Direct (no autograd) call: returns (loss[B], dscores[B,L]).  `cfg` = (owners, dpt,
-    msplit) forces a launch shape (tests / tuning)."""
+    msplit) forces a launch shape (tests / tuning); cfg = "split" takes the workspace entry point
+    (several workgroups per query when the library decides that pays)."""
     s, r, nn = prepare(scores, relevance, n)
     B, L = s.shape
     loss = torch.empty(B, dtype=torch.float32, device=s.device)
     ds = torch.empty(B, L, dtype=torch.float32, device=s.device)
     if B > 0:
         with _C.device_ctx(s):
-            if cfg is None:
+            if cfg == "split":
+                ws_bytes = _C.lib().ltr_pairwise_loss_workspace_bytes(kind, B, L)
+                ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=s.device)
+                rc = _C.lib().ltr_pairwise_loss_ws_f32(
+                    kind, float(sigma), _C.ptr(s), _C.ptr(r), _C.label_dtype(r), _C.ptr(nn),
+                    B, L, _C.ptr(loss), _C.ptr(ds), _C.ptr(ws), ws_bytes, _C.stream_of(s))
+            elif cfg is None:
                 rc = _C.lib().ltr_pairwise_loss_f32(
                     kind, float(sigma), _C.ptr(s), _C.ptr(r), _C.label_dtype(r), _C.ptr(nn),
                     B, L, _C.ptr(loss), _C.ptr(ds), _C.stream_of(s))

@@ -626,20 +626,24 @@ __device__ __forceinline__ float wave_rol1(float v)
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x134, 0xF, 0xF, true));
 }
 
+// part / parts: this workgroup is one of `parts` that share the query's pair units (split-query
+// launch); raw: return the plain pair sum (no loss modifier, gscale untouched).
 template <int KIND>
 __device__ __forceinline__ float pairwise_core_sym(const QueryLds &q, int nb, int Lt, float sigma,
-                                                   float &gscale)
+                                                   float &gscale, int part = 0, int parts = 1,
+                                                   bool raw = false)
 {
     const int tid = threadIdx.x;
     const int T = blockDim.x;
     const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int W = T >> 6;
+    const int wl = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = part * (T >> 6) + wl;                      // wave index among all parts
+    const int W = parts * (T >> 6);
     const int nt = (nb + 63) >> 6;
     const float c1 = sigma * kLog2e;
     constexpr bool kRowWeight = (KIND == LTR_ARP1 || KIND == LTR_NDCG1);
     const float kNaN = __builtin_nanf("");
-    float *gw = q.gpart + (size_t)w * Lt;
+    float *gw = q.gpart + (size_t)wl * Lt;
     for (int i = lane; i < 64 * nt; i += 64) gw[i] = 0.f;
 
     float lacc = 0.f;
@@ -752,11 +756,12 @@ __device__ __forceinline__ float pairwise_core_sym(const QueryLds &q, int nb, in
             j = (a == b) ? 1 : 0;
         }
     }
-    if (kRowWeight)                           // the i == j terms: a_i * log2(1 + e^0) = a_i
+    if (kRowWeight && part == 0)              // the i == j terms: a_i * log2(1 + e^0) = a_i
         for (int k = tid; k < nb; k += T) lacc += q.sy[k].y;
 
     float total = block_sum(lacc, q.red);     // its barriers publish gpart when there are >= 2 waves
     if (T == kWave) __syncthreads();
+    if (raw) return total;
     gscale = 1.0f;
     if (KIND == LTR_DCG_HINGE) {
         const float lg = logf(2.0f + total);
@@ -837,6 +842,103 @@ pairwise_loss_kernel(LossParams p)
 // ---------------------------------------------------------------------------------
 // backward: out[b, j] = grad_out[b] * dscores[b, j]
 // ---------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------
+// Split-query launch for long lists on small batches.  One workgroup per query leaves the time of
+// a launch to its longest query (C4: 256 queries on 256 CUs, n = 1000 takes 55 us, the mean 18);
+// here up to `nsplit` workgroups share one query's pair units (the same unit space the waves of
+// one workgroup share in pairwise_core_sym), each writes its raw pair sum and its gradient
+// slice to the workspace, and a finish kernel adds the parts in order, applies the loss modifier
+// and scales the gradient.  Parts beyond what a short query can use exit at once.
+// workspace: float loss_part[B][nsplit], then float grad_part[B][nsplit][L].
+// ---------------------------------------------------------------------------------
+__host__ __device__ inline int split_parts_for(int nb, int nsplit, int waves)
+{
+    // a part should have at least ~96 pair steps per wave to be worth a workgroup
+    const int nt = (nb + 63) >> 6;
+    const int units = 32 * nt * nt;
+    int e = units / (96 * waves);
+    e = e < 1 ? 1 : e;
+    return e < nsplit ? e : nsplit;
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(1024)
+pairwise_loss_split_kernel(LossParams p, int nsplit, float *ws)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x / nsplit;
+    const int part = blockIdx.x - b * nsplit;
+    const int L = p.L;
+    const int tid = threadIdx.x;
+    const int T = blockDim.x;
+    const int L4 = (L + 63) & ~63;
+    const int msplit = T >> 6;
+    const int nb = clamp_n(p.n[b], L);
+    const int parts = split_parts_for(nb, nsplit, msplit);
+    if (part >= parts) return;                           // uniform: nothing for this workgroup
+    const QueryLds q = carve_query_lds<KIND>(smem, L4, msplit);
+    const size_t row = (size_t)b * L;
+    stage_rows(q.sy, p.scores + row, p.rel, p.rel_dtype, row, L, nb, tid, T);
+    if (KIND == LTR_NDCG1 || KIND == LTR_NDCG2)
+        for (int m = tid; m < 2 * L4; m += T) q.rank_s[m] = 0;
+    __syncthreads();
+    if (KIND == LTR_NDCG1 || KIND == LTR_NDCG2) {
+        int owners = 64;
+        while (owners < L4 && owners < T) owners *= 2;
+        const int ms = T / owners;
+        const int mlen = (nb + ms - 1) / ms;
+        const int m0 = __builtin_amdgcn_readfirstlane(min(nb, (tid / owners) * mlen));
+        const int m1 = __builtin_amdgcn_readfirstlane(min(nb, m0 + mlen));
+        prepare_ndcg<KIND, 1>(q, nb, owners, tid % owners, m0, m1, ms > 1);
+    }
+    float unused = 1.0f;
+    const float raw = pairwise_core_sym<KIND>(q, nb, L4, p.sigma, unused, part, parts, true);
+    float *wl = ws + (size_t)b * nsplit + part;
+    float *wg = ws + (size_t)p.B * nsplit + ((size_t)b * nsplit + part) * L;
+    if (tid == 0) *wl = raw;
+    if (p.dscores != nullptr) {
+        for (int k = tid; k < nb; k += T) {
+            float g = 0.f;
+            for (int s = 0; s < msplit; ++s) g += q.gpart[(size_t)s * L4 + k];
+            wg[k] = g;
+        }
+    }
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256)
+pairwise_loss_finish_kernel(LossParams p, int nsplit, int waves, const float *ws)
+{
+    const int b = blockIdx.x;
+    const int L = p.L;
+    const int nb = clamp_n(p.n[b], L);
+    const int parts = split_parts_for(nb, nsplit, waves);
+    const float *wl = ws + (size_t)b * nsplit;
+    float total = 0.f;
+    for (int s = 0; s < parts; ++s) total += wl[s];      // every thread, same order
+    float gscale = 1.0f;
+    if (KIND == LTR_DCG_HINGE) {
+        const float lg = logf(2.0f + total);
+        gscale = 1.0f / ((2.0f + total) * lg * lg);
+        total = -1.0f / lg;
+    } else if (KIND != LTR_HINGE) {
+        gscale = p.sigma / kLn2;
+    }
+    if (threadIdx.x == 0) p.loss[b] = total;
+    if (p.dscores != nullptr) {
+        const float *wg = ws + (size_t)p.B * nsplit + (size_t)b * nsplit * L;
+        float *out = p.dscores + (size_t)b * L;
+        for (int k = threadIdx.x; k < L; k += blockDim.x) {
+            float g = 0.f;
+            if (k < nb) {
+                for (int s = 0; s < parts; ++s) g += wg[(size_t)s * L + k];
+                g *= gscale;
+            }
+            out[k] = g;
+        }
+    }
+}
+
 __global__ void scale_rows_kernel(const float *__restrict__ ds, const float *__restrict__ go,
                                   size_t total, int L, float *__restrict__ out)
 {
@@ -1302,6 +1404,49 @@ int launch_loss(int kind, const LossParams &p, const LaunchShape &s, hipStream_t
     }
 }
 
+inline int device_cu_count()
+{
+    static int cached[kMaxDevices] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= kMaxDevices) dev = 0;
+    if (cached[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        cached[dev] = v;
+    }
+    return cached[dev];
+}
+
+// How many workgroups share a query in the split launch (1 = use the one-kernel path): long lists
+// only, and only while the batch alone cannot give every CU several queries to balance with.
+constexpr int kSplitWaves = 4;       // waves per part: small workgroups, many per CU
+static int choose_loss_splits(int kind, int B, int L)
+{
+    if (L <= 256 || L > kSymMaxLen) return 1;
+    // the NDCG kinds would repeat their two rankings in every part: they keep the plain path
+    if (kind == LTR_NDCG1 || kind == LTR_NDCG2) return 1;
+    const int cus = device_cu_count();
+    if (2 * B > 3 * cus) return 1;       // measured: no gain once the batch has > 1.5 queries per CU
+    int s = (8 * cus) / (B > 0 ? B : 1);
+    if (s > 8) s = 8;
+    return s < 2 ? 1 : s;
+}
+
+template <int KIND>
+static int launch_loss_split(const LossParams &p, int nsplit, float *ws, hipStream_t stream)
+{
+    const int waves = kSplitWaves;
+    const size_t lds = loss_lds_bytes(KIND, (p.L + 63) & ~63, waves);
+    LTR_ENSURE_LDS((pairwise_loss_split_kernel<KIND>), lds);
+    hipLaunchKernelGGL((pairwise_loss_split_kernel<KIND>), dim3((unsigned)(p.B * nsplit)), dim3(64 * waves),
+                       lds, stream, p, nsplit, ws);
+    hipLaunchKernelGGL((pairwise_loss_finish_kernel<KIND>), dim3((unsigned)p.B), dim3(256), 0, stream, p,
+                       nsplit, waves, (const float *)ws);
+    return (int)hipGetLastError();
+}
+
 template <int OP>
 int launch_metric(const MetricParams &p0, hipStream_t stream)
 {
@@ -1414,6 +1559,44 @@ int ltr_pairwise_loss_f32(int kind, float sigma, const float *scores, const void
     return ltr_pairwise_loss_f32_cfg(kind, sigma, scores, rel, rel_dtype, n, B, L, loss, dscores,
                                      s.owners, s.dpt, s.msplit, stream);
 }
+
+size_t ltr_pairwise_loss_workspace_bytes(int kind, int B, int L)
+{
+    if (B <= 0 || L <= 0) return 0;
+    const int nsplit = choose_loss_splits(kind, B, L);
+    if (nsplit <= 1) return 0;
+    return (size_t)B * nsplit * ((size_t)L + 1) * sizeof(float);
+}
+
+int ltr_pairwise_loss_ws_f32(int kind, float sigma, const float *scores, const void *rel,
+                             int rel_dtype, const int64_t *n, int B, int L, float *loss,
+                             float *dscores, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (kind < LTR_HINGE || kind > LTR_NDCG2 || bad_label_dtype(rel_dtype)) return LTR_ERR_KIND;
+    if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
+    if (L > kMaxListLen) return LTR_ERR_LIST_TOO_LONG;
+    if (B == 0) return LTR_OK;
+    if (!scores || !rel || !n || !loss) return LTR_ERR_NULL;
+    const int nsplit = choose_loss_splits(kind, B, L);
+    if (nsplit <= 1)
+        return ltr_pairwise_loss_f32(kind, sigma, scores, rel, rel_dtype, n, B, L, loss, dscores, stream);
+    if (!workspace || workspace_bytes < ltr_pairwise_loss_workspace_bytes(kind, B, L)) return LTR_ERR_WORKSPACE;
+    LossParams p;
+    p.scores = scores; p.rel = rel; p.n = n; p.loss = loss; p.dscores = dscores;
+    p.B = B; p.L = L; p.sigma = sigma; p.rel_dtype = rel_dtype; p.msplit = kSplitWaves;
+    float *ws = (float *)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    switch (kind) {
+    case LTR_HINGE: return launch_loss_split<LTR_HINGE>(p, nsplit, ws, st);
+    case LTR_DCG_HINGE: return launch_loss_split<LTR_DCG_HINGE>(p, nsplit, ws, st);
+    case LTR_LOGISTIC: return launch_loss_split<LTR_LOGISTIC>(p, nsplit, ws, st);
+    case LTR_ARP1: return launch_loss_split<LTR_ARP1>(p, nsplit, ws, st);
+    case LTR_ARP2: return launch_loss_split<LTR_ARP2>(p, nsplit, ws, st);
+    case LTR_NDCG1: return launch_loss_split<LTR_NDCG1>(p, nsplit, ws, st);
+    default: return launch_loss_split<LTR_NDCG2>(p, nsplit, ws, st);
+    }
+}
+
 
 int ltr_scale_rows_f32(const float *dscores, const float *grad_out, int B, int L, float *out,
                        void *stream)

@@ -19,5 +19,15 @@ for B, L in shapes:
         for _ in range(5):
             fn()
         t, _ = time_launches(fn, per_graph=20, replays=10)
-        res.append("%s %.1f" % (k, t))
+        wsb = lib.ltr_pairwise_loss_workspace_bytes(kid, B, L)
+        if wsb > 0:
+            ws = torch.empty(wsb // 4, device=dev)
+            fs = lambda: _C.check(lib.ltr_pairwise_loss_ws_f32(kid, 1.0, scores.data_ptr(), rel.data_ptr(), 0, n.data_ptr(), B, L,
+                                                               loss.data_ptr(), ds.data_ptr(), ws.data_ptr(), wsb, torch.cuda.current_stream().cuda_stream))
+            for _ in range(5):
+                fs()
+            t2, _ = time_launches(fs, per_graph=20, replays=10)
+            res.append("%s %.1f (split %.1f)" % (k, t, t2))
+        else:
+            res.append("%s %.1f" % (k, t))
     print("B=%d L=%d | " % (B, L) + " | ".join(res) + "  (us)", flush=True)

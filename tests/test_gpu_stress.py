@@ -148,3 +148,32 @@ def test_sorted_ranks_with_ties_on_long_lists(L):
     for fn, ofn in ((lambda: ndcg(scores.to(dev), y0.to(dev), n.to(dev), k=10), lambda: O.ndcg(scores.numpy(), y0.numpy(), n.numpy(), k=10)),
                     (lambda: arp(scores.to(dev), y0.to(dev), n.to(dev)), lambda: O.arp(scores.numpy(), y0.numpy(), n.numpy()))):
         assert np.allclose(fn().cpu().numpy(), ofn(), rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("shape", [(24, 1000), (256, 1000), (40, 300), (5, 1024), (64, 700)])
+def test_split_query_launch_matches_single_workgroup(kind, shape):
+    """ltr_pairwise_loss_ws_f32 (several workgroups share a long query, parts added in a fixed
+    order by a finish kernel) against the one-workgroup-per-query kernel: same loss to fp32
+    summation-order round-off, same gradient; hinge gradients (integers) bit-exact; padded slots
+    exactly zero; and against the oracle on a few rows."""
+    from pytorchltr_amd import _C
+    from pytorchltr_amd._autograd import pairwise_loss_and_grad
+    dev = torch.device("cuda")
+    B, L = shape
+    scores, y, n = synth(B, L, 17 + L)
+    n[:4] = torch.tensor([L, 1, 0, 65])[:min(4, B)]
+    kid = getattr(_C, kind.upper())
+    a_l, a_g = pairwise_loss_and_grad(scores.to(dev), y.to(dev), n.to(dev), kid)
+    b_l, b_g = pairwise_loss_and_grad(scores.to(dev), y.to(dev), n.to(dev), kid, cfg="split")
+    assert torch.allclose(a_l, b_l, rtol=2e-5, atol=1e-5)
+    scale = a_g.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+    assert bool(((a_g - b_g).abs() <= 2e-5 * scale + 1e-6).all())
+    if kind == "hinge":
+        assert torch.equal(a_g, b_g)
+    pad = torch.arange(L)[None, :] >= n.clamp(max=L)[:, None]
+    assert not b_g.cpu()[pad].any()
+    rows = slice(0, min(B, 6))
+    want_l, want_g = O.pairwise_loss(kind, scores[rows].numpy(), y[rows].numpy(), n[rows].numpy())
+    _check_loss(b_l[rows].cpu().numpy(), want_l, L, kind)
+    _check_grad(b_g[rows].cpu().numpy(), want_g, kind)
