@@ -177,3 +177,26 @@ def test_split_query_launch_matches_single_workgroup(kind, shape):
     want_l, want_g = O.pairwise_loss(kind, scores[rows].numpy(), y[rows].numpy(), n[rows].numpy())
     _check_loss(b_l[rows].cpu().numpy(), want_l, L, kind)
     _check_grad(b_g[rows].cpu().numpy(), want_g, kind)
+
+
+def test_split_query_launch_through_the_module_and_forward_only():
+    """The loss modules take the split launch by themselves for long lists on small batches:
+    forward-only (no gradient buffer) and forward+backward agree with the direct kernel."""
+    from pytorchltr_amd import _C
+    from pytorchltr_amd._autograd import pairwise_loss_and_grad
+    from pytorchltr_amd.loss import PairwiseLogisticLoss
+    dev = torch.device("cuda")
+    B, L = 16, 900
+    assert _C.lib().ltr_pairwise_loss_workspace_bytes(_C.LOGISTIC, B, L) > 0
+    scores, y, n = synth(B, L, 3)
+    ref_l, ref_g = pairwise_loss_and_grad(scores.to(dev), y.to(dev), n.to(dev), _C.LOGISTIC)
+    loss_fn = PairwiseLogisticLoss()
+    with torch.no_grad():
+        fwd = loss_fn(scores.to(dev), y.to(dev), n.to(dev))
+    assert torch.allclose(fwd, ref_l, rtol=2e-5, atol=1e-5)
+    s = scores.to(dev).requires_grad_(True)
+    out = loss_fn(s, y.to(dev), n.to(dev))
+    out.sum().backward()
+    assert torch.allclose(out.detach(), ref_l, rtol=2e-5, atol=1e-5)
+    scale = ref_g.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+    assert bool(((s.grad - ref_g).abs() <= 2e-5 * scale + 1e-6).all())
