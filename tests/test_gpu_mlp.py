@@ -219,3 +219,18 @@ def test_against_reference_fp32_outputs(kind):
     for got, name in zip(grads, names):
         want = z["%s/%s/grad/%s" % (tag, kind, name)]
         assert np.abs(got.cpu().numpy().reshape(want.shape) - want).max() <= 5e-5 * scale + 1e-6, (kind, name)
+
+
+def test_several_scheduling_blocks_guide_network():
+    """B = 2500 = two full 1024-query scheduling blocks + a partial one (n-sorted snake
+    assignment per block), guide-sized network, ragged n with zeros: against the oracle."""
+    X, y, n, params = _case(2500, 128, 136, 50, 10, 31)
+    n[::97] = 0
+    n[5::211] = 128
+    _check("hinge", X, y, n, params)
+
+
+def test_uniform_n_blocks_skip_the_sort():
+    """All queries of a block with the same n (full lists) take the round-robin shortcut."""
+    X, y, n, params = _case(1100, 64, 32, 16, 4, 9, full=True)
+    _check("logistic", X, y, n, params)
