@@ -851,12 +851,21 @@ pairwise_loss_kernel(LossParams p)
 // and scales the gradient.  Parts beyond what a short query can use exit at once.
 // workspace: float loss_part[B][nsplit], then float grad_part[B][nsplit][L].
 // ---------------------------------------------------------------------------------
+#ifndef LTR_SPLIT_WAVES
+#define LTR_SPLIT_WAVES 4
+#endif
+#ifndef LTR_SPLIT_MAX
+#define LTR_SPLIT_MAX 8
+#endif
+#ifndef LTR_SPLIT_MIN_STEPS
+#define LTR_SPLIT_MIN_STEPS 48
+#endif
 __host__ __device__ inline int split_parts_for(int nb, int nsplit, int waves)
 {
-    // a part should have at least ~96 pair steps per wave to be worth a workgroup
+    // a part should have at least ~48 pair steps per wave to be worth a workgroup (swept)
     const int nt = (nb + 63) >> 6;
     const int units = 32 * nt * nt;
-    int e = units / (96 * waves);
+    int e = units / (LTR_SPLIT_MIN_STEPS * waves);
     e = e < 1 ? 1 : e;
     return e < nsplit ? e : nsplit;
 }
@@ -1421,7 +1430,7 @@ inline int device_cu_count()
 
 // How many workgroups share a query in the split launch (1 = use the one-kernel path): long lists
 // only, and only while the batch alone cannot give every CU several queries to balance with.
-constexpr int kSplitWaves = 4;       // waves per part: small workgroups, many per CU
+constexpr int kSplitWaves = LTR_SPLIT_WAVES;   // waves per part: small workgroups, many per CU
 static int choose_loss_splits(int kind, int B, int L)
 {
     if (L <= 256 || L > kSymMaxLen) return 1;
@@ -1429,8 +1438,8 @@ static int choose_loss_splits(int kind, int B, int L)
     if (kind == LTR_NDCG1 || kind == LTR_NDCG2) return 1;
     const int cus = device_cu_count();
     if (2 * B > 3 * cus) return 1;       // measured: no gain once the batch has > 1.5 queries per CU
-    int s = (8 * cus) / (B > 0 ? B : 1);
-    if (s > 8) s = 8;
+    int s = (LTR_SPLIT_MAX * cus) / (B > 0 ? B : 1);
+    if (s > LTR_SPLIT_MAX) s = LTR_SPLIT_MAX;
     return s < 2 ? 1 : s;
 }
 
