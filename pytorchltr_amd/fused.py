@@ -244,7 +244,8 @@ class _MLPLossFunction(torch.autograd.Function):
         loss = _KindProxy(*kind_sigma)
         lossv, grads, lsum = mlp_loss_step(xs, params, relevance, n, loss=loss, grad_out=go,
                                            return_loss_sum=True)
-        ctx.save_for_backward(*grads)
+        ctx.save_for_backward(grads[0]._base)       # the flat buffer: one scale in backward
+        ctx.dims = (xs.shape[2], params[0].shape[0], params[2].shape[0])
         ctx.shapes = [p.shape for p in params]
         ctx.per_query = lossv
         total = lsum.reshape(())
@@ -255,8 +256,9 @@ class _MLPLossFunction(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_total, grad_unused):
-        grads = ctx.saved_tensors
-        scaled = tuple((g * grad_total).reshape(s) for g, s in zip(grads, ctx.shapes))
+        (flat,) = ctx.saved_tensors
+        parts = _split_grads(flat * grad_total, *ctx.dims)
+        scaled = tuple(g.reshape(s) for g, s in zip(parts, ctx.shapes))
         return (None, None, None, None, None) + scaled
 
 
