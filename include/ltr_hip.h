@@ -237,6 +237,14 @@ int ltr_mlp_pairwise_f32(int kind, float sigma, const float *X, const float *W1,
                          float *grads, float *loss_sum, void *workspace, size_t workspace_bytes,
                          void *stream);
 
+/* The same network, forward only: scores_out (B,L) = model(X) for documents < n[b], 0 for the
+ * padded ones -- the `model(xs)` of the guide's evaluation loop (docs/source/getting-started.rst:
+ * 117-127) without the rocBLAS round trips.  Same shape limits as ltr_mlp_pairwise_f32; no
+ * workspace. */
+int ltr_mlp_scores_f32(const float *X, const float *W1, const float *b1, const float *W2,
+                       const float *b2, const float *W3, const float *b3, const int64_t *n, int B,
+                       int L, int F, int H1, int H2, float *scores_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

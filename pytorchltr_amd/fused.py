@@ -233,6 +233,26 @@ def mlp_loss_step(xs, params, relevance, n, loss="hinge", grad_out=None, return_
     return res
 
 
+def mlp_scores(xs, params, n=None):
+    """``model(xs)`` of the guide's network as one fused kernel (no autograd): (B, L) float32
+    scores for documents < n[b] and 0 for the padded ones; n=None scores every document.
+    Shapes outside the kernel's limits raise ValueError (see :func:`mlp_supported`)."""
+    X = _prepare_features(xs)
+    B, L, F = X.shape
+    flat_params, H1, H2 = _flat_params(params, F)
+    if not mlp_supported(L, F, H1, H2):
+        raise ValueError("fused MLP kernel takes L <= %d, F <= %d with F %% 4 == 0, hidden <= %s"
+                         % (MLP_MAX_LIST_LEN, MLP_MAX_FEATURES, MLP_MAX_HIDDEN))
+    nn = (torch.full((B,), L, dtype=torch.int64, device=X.device) if n is None else prepare_n(n, B))
+    scores = torch.empty(B, L, dtype=torch.float32, device=X.device)
+    if B > 0:
+        with _C.device_ctx(X):
+            _C.check(_C.lib().ltr_mlp_scores_f32(
+                _C.ptr(X), *[_C.ptr(t) for t in flat_params], _C.ptr(nn), B, L, F, H1, H2,
+                _C.ptr(scores), _C.stream_of(X)))
+    return scores
+
+
 class _MLPLossFunction(torch.autograd.Function):
     """Reduced (mean / sum) loss of the fused MLP step; the kernel already produced the parameter
     gradients of the reduced loss, backward only scales them by the incoming scalar."""
@@ -292,7 +312,13 @@ class FusedMLPLoss(torch.nn.Module):
         self.l3 = torch.nn.Linear(hidden[1], 1)
         self.last_losses = None
 
-    def score(self, xs):
+    def score(self, xs, n=None):
+        """``model(xs)``: (B, L, 1) scores.  Under ``torch.no_grad()`` (evaluation) and for shapes
+        the fused kernel takes it is one launch (padded documents, when ``n`` is given, score 0);
+        otherwise the three ``nn.Linear`` layers, with autograd."""
+        if (not torch.is_grad_enabled() and xs.dim() == 3 and xs.is_cuda
+                and mlp_supported(xs.shape[1], xs.shape[2], self.l1.out_features, self.l2.out_features)):
+            return mlp_scores(xs, self._params(), n).unsqueeze(-1)
         o1 = torch.nn.functional.relu(self.l1(xs))
         o2 = torch.nn.functional.relu(self.l2(o1))
         return self.l3(o2)

@@ -74,6 +74,27 @@ def main():
         "padded_tile_tflops": B * L * flops_per_doc / (us * 1e-6) / 1e12,
         "feature_stream_GBs": docs * F * 4 / (us * 1e-6) / 1e9,
     }
+    # forward only (evaluation): fused scores kernel vs the three torch layers
+    from pytorchltr_amd.fused import mlp_scores
+    sc = torch.empty(B, L, device=dev)
+
+    def launch_scores():
+        _C.check(lib.ltr_mlp_scores_f32(X.data_ptr(), *[p.data_ptr() for p in params], n.data_ptr(),
+                                        B, L, F, H1, H2, sc.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    for _ in range(5):
+        launch_scores()
+    us_s, _ = bench.time_launches(launch_scores, per_graph=10, replays=10)
+    out["scores_only_us"] = us_s
+
+    def torch_scores():
+        with torch.no_grad():
+            h = torch.relu(torch.nn.functional.linear(X, m.l1.weight, m.l1.bias))
+            h = torch.relu(torch.nn.functional.linear(h, m.l2.weight, m.l2.bias))
+            return torch.nn.functional.linear(h, m.l3.weight, m.l3.bias)
+    for _ in range(5):
+        torch_scores()
+    us_t, _ = bench.time_launches(torch_scores, per_graph=5, replays=10)
+    out["scores_only_torch_layers_us"] = us_t
     if not args.no_unfused:
         loss_fn = {"hinge": L_.PairwiseHingeLoss, "dcg_hinge": L_.PairwiseDCGHingeLoss,
                    "logistic": L_.PairwiseLogisticLoss, "arp1": L_.LambdaARPLoss1,

@@ -234,3 +234,42 @@ def test_uniform_n_blocks_skip_the_sort():
     """All queries of a block with the same n (full lists) take the round-robin shortcut."""
     X, y, n, params = _case(1100, 64, 32, 16, 4, 9, full=True)
     _check("logistic", X, y, n, params)
+
+
+@pytest.mark.parametrize("shape", [(16, 20, 136, 50, 10), (300, 128, 136, 50, 10), (5, 77, 220, 64, 16), (3, 128, 8, 3, 1)])
+def test_forward_only_scores(shape):
+    """ltr_mlp_scores_f32 (the evaluation half of the guide's workflow) against the three torch
+    layers: fp32 round-off; padded documents score exactly 0; n=None scores everything."""
+    from pytorchltr_amd import fused
+    dev = torch.device("cuda")
+    B, L, F, H1, H2 = shape
+    X, y, n, params = _case(B, L, F, H1, H2, 55 + L)
+    n[0] = L
+    if B > 2:
+        n[1] = 0
+    P = [p.to(dev) for p in params]
+    Xd = X.to(dev)
+    h = torch.relu(Xd @ P[0].t() + P[1])
+    h = torch.relu(h @ P[2].t() + P[3])
+    want = (h @ P[4].t() + P[5]).squeeze(-1)
+    got = fused.mlp_scores(Xd, P, n.to(dev))
+    valid = (torch.arange(L)[None, :] < n[:, None]).to(dev)
+    assert torch.allclose(got[valid], want[valid], rtol=1e-5, atol=2e-6)
+    assert not got[~valid].any()
+    assert torch.allclose(fused.mlp_scores(Xd, P), want, rtol=1e-5, atol=2e-6)
+
+
+def test_module_score_uses_the_fused_kernel_under_no_grad():
+    from pytorchltr_amd.evaluation import ndcg
+    from pytorchltr_amd.fused import FusedMLPLoss
+    dev = torch.device("cuda")
+    X, y, n, _ = _case(32, 40, 136, 50, 10, 6)
+    m = FusedMLPLoss(136, "hinge").to(dev)
+    with torch.no_grad():
+        fast = m.score(X.to(dev), n.to(dev))
+    slow = m.score(X.to(dev))                       # grad enabled: the nn.Linear layers
+    assert fast.shape == slow.shape == (32, 40, 1) and slow.requires_grad and not fast.requires_grad
+    valid = (torch.arange(40)[None, :] < n[:, None]).to(dev)
+    assert torch.allclose(fast.squeeze(-1)[valid], slow.detach().squeeze(-1)[valid], rtol=1e-5, atol=2e-6)
+    y0 = (y * (torch.arange(40)[None, :] < n[:, None])).to(dev)
+    assert torch.allclose(ndcg(fast, y0, n.to(dev), k=10), ndcg(slow.detach(), y0, n.to(dev), k=10), atol=1e-6)
