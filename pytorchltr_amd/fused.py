@@ -163,6 +163,16 @@ def mlp_supported(L, F, H1, H2):
             and 0 < H1 <= MLP_MAX_HIDDEN[0] and 0 < H2 <= MLP_MAX_HIDDEN[1])
 
 
+def _pad_features(xs, w1):
+    """Feature counts that are not a multiple of 4 (MQ2007: 46, Yahoo: 699): zero columns are
+    appended to the features and to W1 -- same scores, and the extra dW1 columns are dropped.  Costs
+    one copy of the batch; pad the stored split once to avoid it."""
+    extra = (-xs.shape[-1]) % 4
+    if extra == 0:
+        return xs, w1, 0
+    return (torch.nn.functional.pad(xs, (0, extra)), torch.nn.functional.pad(w1, (0, extra)), extra)
+
+
 def _flat_params(params, F):
     W1, b1, W2, b2, W3, b3 = [t.detach().float().contiguous() for t in params]
     H1, H2 = W1.shape[0], W2.shape[0]
@@ -262,10 +272,12 @@ class _MLPLossFunction(torch.autograd.Function):
         B = xs.shape[0]
         go = None if mean else torch.ones(B, dtype=torch.float32, device=xs.device)
         loss = _KindProxy(*kind_sigma)
-        lossv, grads, lsum = mlp_loss_step(xs, params, relevance, n, loss=loss, grad_out=go,
-                                           return_loss_sum=True)
+        xs, w1, extra = _pad_features(xs, params[0].detach())
+        lossv, grads, lsum = mlp_loss_step(xs, (w1,) + tuple(params[1:]), relevance, n, loss=loss,
+                                           grad_out=go, return_loss_sum=True)
         ctx.save_for_backward(grads[0]._base)       # the flat buffer: one scale in backward
         ctx.dims = (xs.shape[2], params[0].shape[0], params[2].shape[0])
+        ctx.extra = extra
         ctx.shapes = [p.shape for p in params]
         ctx.per_query = lossv
         total = lsum.reshape(())
@@ -277,7 +289,9 @@ class _MLPLossFunction(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, grad_total, grad_unused):
         (flat,) = ctx.saved_tensors
-        parts = _split_grads(flat * grad_total, *ctx.dims)
+        parts = list(_split_grads(flat * grad_total, *ctx.dims))
+        if ctx.extra:
+            parts[0] = parts[0][:, :ctx.dims[0] - ctx.extra]
         scaled = tuple(g.reshape(s) for g, s in zip(parts, ctx.shapes))
         return (None, None, None, None, None) + scaled
 
@@ -295,8 +309,9 @@ class FusedMLPLoss(torch.nn.Module):
     *reduced* loss ``loss_fn(model(xs), relevance, n).mean()`` (or ``.sum()``) whose backward
     fills the six parameter gradients -- computed by one fused MFMA kernel.
 
-    Shapes the kernel does not take (lists longer than 128, more than 224 features, ...) run as
-    the unfused composition: rocBLAS layers + the HIP loss kernel.  ``score(xs)`` evaluates the
+    Feature counts that are not a multiple of 4 are zero-padded on the fly.  Shapes the kernel
+    does not take (lists longer than 128, more than 224 features, ...) run as the unfused
+    composition: rocBLAS layers + the HIP loss kernel.  ``score(xs)`` evaluates the
     network alone (for the metrics).
     """
 
@@ -317,8 +332,10 @@ class FusedMLPLoss(torch.nn.Module):
         the fused kernel takes it is one launch (padded documents, when ``n`` is given, score 0);
         otherwise the three ``nn.Linear`` layers, with autograd."""
         if (not torch.is_grad_enabled() and xs.dim() == 3 and xs.is_cuda
-                and mlp_supported(xs.shape[1], xs.shape[2], self.l1.out_features, self.l2.out_features)):
-            return mlp_scores(xs, self._params(), n).unsqueeze(-1)
+                and mlp_supported(xs.shape[1], (xs.shape[2] + 3) & ~3, self.l1.out_features,
+                                  self.l2.out_features)):
+            xp, w1, _ = _pad_features(xs, self.l1.weight.detach())
+            return mlp_scores(xp, (w1,) + self._params()[1:], n).unsqueeze(-1)
         o1 = torch.nn.functional.relu(self.l1(xs))
         o2 = torch.nn.functional.relu(self.l2(o1))
         return self.l3(o2)
@@ -330,7 +347,7 @@ class FusedMLPLoss(torch.nn.Module):
     def forward(self, xs, relevance, n):
         _C.require_device(xs, "xs")
         B, L, F = xs.shape
-        if mlp_supported(L, F, self.l1.out_features, self.l2.out_features):
+        if mlp_supported(L, (F + 3) & ~3, self.l1.out_features, self.l2.out_features):
             total, per_query = _MLPLossFunction.apply(
                 xs, relevance, n, (self.kind, self.sigma), self.reduction == "mean", *self._params())
             self.last_losses = per_query

@@ -289,3 +289,29 @@ def test_getting_started_example_learns():
     trace = mod.run(epochs=3, log=lambda msg: None)
     assert len(trace) == 4
     assert trace[-1] > trace[0] + 0.05, trace
+
+
+@pytest.mark.parametrize("F", [5, 46, 135])
+def test_module_pads_feature_counts_that_are_not_multiples_of_four(F):
+    """MQ2007 has 46 features, Example3 5: the module zero-pads features and W1 for the kernel
+    and returns gradients in the original shapes -- same step as the unfused composition."""
+    from pytorchltr_amd.fused import FusedMLPLoss
+    from pytorchltr_amd.loss import PairwiseHingeLoss
+    dev = torch.device("cuda")
+    X, y, n, _ = _case(12, 30, F, 50, 10, 70 + F)
+    torch.manual_seed(F)
+    fusedm = FusedMLPLoss(F, "hinge").to(dev)
+    plain = FusedMLPLoss(F, "hinge").to(dev)
+    plain.load_state_dict(fusedm.state_dict())
+    out = fusedm(X.to(dev), y.to(dev), n.to(dev))
+    out.backward()
+    ref = PairwiseHingeLoss()(plain.score(X.to(dev)), y.to(dev), n.to(dev)).mean()
+    ref.backward()
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-6)
+    scale = max(float(b.grad.abs().max()) for b in plain.parameters())
+    for a, b in zip(fusedm.parameters(), plain.parameters()):
+        assert a.grad.shape == b.grad.shape
+        assert torch.allclose(a.grad, b.grad, rtol=2e-4, atol=2e-5 * max(1.0, scale))
+    with torch.no_grad():
+        assert torch.allclose(fusedm.score(X.to(dev), n.to(dev))[:, :1], plain.score(X.to(dev))[:, :1].detach(),
+                              rtol=1e-5, atol=2e-6)
