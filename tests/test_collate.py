@@ -127,3 +127,42 @@ def test_dataloader_training_loop_on_device_collate():
             loss_fn(model(batch.features), batch.relevance, batch.n).mean().backward()
             opt.step()
     assert evaluate() > before + 0.05
+
+
+def _grade_histogram(sampler, relevance, position, draws=1000):
+    hist = torch.zeros(3)
+    for _ in range(draws):
+        hist[int(relevance[sampler(relevance)][position])] += 1
+    return (hist / draws).tolist()
+
+
+def test_sampler_distributions_match_the_reference_expectations():
+    """The distributions the reference's own sampler tests pin
+    (tests/datasets/test_list_sampler.py:84-111, 158-198): a uniform sampler picks grades in
+    proportion to their frequency at every output position; the balanced sampler cycles through
+    the grades while they last (1/3 each, then 1/2 each once grade 2 is exhausted, then only 0)."""
+    seed = 1608637542
+    rel = torch.tensor([0, 0, 1, 0, 0, 0, 2, 1])
+    for size, positions in ((1, [0]), (5, range(5))):
+        sampler = UniformSampler(max_list_size=size, generator=torch.Generator().manual_seed(seed))
+        for pos in positions:
+            assert _grade_histogram(sampler, rel, pos) == pytest.approx([5 / 8, 2 / 8, 1 / 8], abs=0.05)
+    sampler = BalancedRelevanceSampler(max_list_size=1, generator=torch.Generator().manual_seed(seed))
+    assert _grade_histogram(sampler, rel, 0) == pytest.approx([1 / 3, 1 / 3, 1 / 3], abs=0.05)
+    rel11 = torch.tensor([0, 0, 1, 0, 0, 0, 2, 1, 0, 0, 0])
+    sampler = BalancedRelevanceSampler(max_list_size=7, generator=torch.Generator().manual_seed(seed))
+    expected = [[1 / 3] * 3] * 3 + [[0.5, 0.5, 0.0]] * 2 + [[1.0, 0.0, 0.0]] * 2
+    for pos in range(7):
+        assert _grade_histogram(sampler, rel11, pos) == pytest.approx(expected[pos], abs=0.05)
+
+
+def test_sampler_sizes_and_global_rng():
+    rel = torch.tensor([0, 1, 0, 0, 2, 0, 1, 0, 0, 0])
+    torch.manual_seed(1608637542)                                   # no generator: global RNG
+    assert UniformSampler(max_list_size=5)(rel).shape == (5,)
+    assert BalancedRelevanceSampler(max_list_size=5)(rel).shape == (5,)
+    g = torch.Generator().manual_seed(3)
+    assert UniformSampler(max_list_size=9, generator=g)(torch.tensor([0, 1])).shape == (2,)
+    assert UniformSampler(max_list_size=None, generator=g)(rel).shape == (10,)
+    assert BalancedRelevanceSampler(max_list_size=None, generator=g)(rel).shape == (10,)
+    assert ListSampler(max_list_size=1)(torch.tensor([0])).tolist() == [0]
