@@ -24,7 +24,7 @@ class GraphedStep:
 
     Args:
         params_owner: the ``torch.nn.Module`` (or an iterable of parameters) being trained.
-        optimizer: a torch optimizer; stateful ones (Adagrad, Adam, ...) must be built with
+        optimizer: a torch optimizer; stateful ones that keep a step counter (Adam, ...) must be built with
             ``capturable=True`` so that their step counters live on the device.
         loss_closure: maps the static batch tensors to a scalar loss.
         example_batch: tensors with the shapes / dtypes / device of every later batch.
