@@ -75,7 +75,6 @@ def main():
         "feature_stream_GBs": docs * F * 4 / (us * 1e-6) / 1e9,
     }
     # forward only (evaluation): fused scores kernel vs the three torch layers
-    from pytorchltr_amd.fused import mlp_scores
     sc = torch.empty(B, L, device=dev)
 
     def launch_scores():
