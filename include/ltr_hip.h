@@ -245,6 +245,20 @@ int ltr_mlp_scores_f32(const float *X, const float *W1, const float *b1, const f
                        const float *b2, const float *W3, const float *b3, const int64_t *n, int B,
                        int L, int F, int H1, int H2, float *scores_out, void *stream);
 
+/* --- the Linear(F, 1) scorer on its own ---------------------------------------------------
+ * For the UNFUSED drop-in composition `loss_fn(model(xs), ys, n)` with `model` =
+ * torch.nn.Linear(F, 1) (examples/01-basic-usage.py:45, tests/test_integration.py:30): on ROCm that
+ * layer is a one-column rocBLAS GEMM far below HBM speed; these two kernels stream X once each.
+ *   scores (B,L) = X.W + bias; documents >= n[b] score 0 and are not read (n may be NULL: all rows).
+ *   dW_db (F+1) = [sum_r g[r] X[r,:] | sum_r g[r]] for the upstream gradient g (B,L) of the scores;
+ *   rows with g == 0 or >= n[b] are not read.  F <= 1024 (scores).  workspace:
+ *   ltr_linear_grad_workspace_bytes(B,L,F) bytes.  Deterministic (fixed-order partial sums). */
+int ltr_linear_scores_f32(const float *X, const float *W, const float *bias, const int64_t *n, int B,
+                          int L, int F, float *scores, void *stream);
+size_t ltr_linear_grad_workspace_bytes(int B, int L, int F);
+int ltr_linear_grad_f32(const float *X, const float *g, const int64_t *n, int B, int L, int F,
+                        float *dW_db, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

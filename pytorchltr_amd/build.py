@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libltr_hip.so")
 SOURCES = [os.path.join(CSRC, "ltr_kernels.hip")]
 DEPENDS = SOURCES + [os.path.join(CSRC, "ltr_linear.inc"), os.path.join(CSRC, "ltr_f64.inc"),
-                     os.path.join(CSRC, "ltr_mlp.inc"),
+                     os.path.join(CSRC, "ltr_mlp.inc"), os.path.join(CSRC, "ltr_scorer.inc"),
                      os.path.join(_ROOT, "include", "ltr_hip.h")]
 ARCH = "gfx950"
 IO_LIB_PATH = os.path.join(CSRC, "libltr_io.so")

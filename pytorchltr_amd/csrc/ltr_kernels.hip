@@ -1750,3 +1750,4 @@ int ltr_collate_pad_f32(const float *xs, const int64_t *ys, const int64_t *offse
 #include "ltr_linear.inc"
 #include "ltr_f64.inc"
 #include "ltr_mlp.inc"
+#include "ltr_scorer.inc"

@@ -108,8 +108,23 @@ class FusedLinearLoss(torch.nn.Module):
             torch.nn.init.uniform_(self.bias, -bound, bound)
 
     def forward(self, xs, relevance, n, return_scores=False):
+        if xs.dim() == 3 and xs.is_cuda and self._prefer_pieces(xs.shape[0], xs.shape[1]):
+            # a few long lists: one workgroup per query cannot fill the GPU; the balanced pieces
+            # (streaming scorer, split-query loss, streaming weight gradient) are faster
+            from ._autograd import PairwiseLossFunction
+            scores = _LinearScoreFunction.apply(xs, self.weight, self.bias, n)
+            loss = PairwiseLossFunction.apply(scores, relevance, n, self.kind, self.sigma)
+            return (loss, scores.detach().squeeze(-1)) if return_scores else loss
         return _LinearLossFunction.apply(xs, self.weight, self.bias, relevance, n, self.kind,
                                          self.sigma, bool(return_scores))
+
+    def _prefer_pieces(self, B, L):
+        # measured on MI355X (scripts/bench_scorer.py): 32 x 1000 x 220 pieces 71 us vs fused 95;
+        # 256 x 1000 x 220 pieces 120 us vs fused 104
+        if B <= 0 or _C.lib().ltr_pairwise_loss_workspace_bytes(self.kind, B, L) == 0:
+            return False
+        cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+        return 2 * B <= cus
 
 
 def linear_loss_step(xs, weight, bias, relevance, n, loss="hinge", grad_out=None,
@@ -147,6 +162,64 @@ def linear_loss_step(xs, weight, bias, relevance, n, loss="hinge", grad_out=None
     if return_loss_sum:
         out = out + (lsum,)
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# The Linear(F, 1) scorer on its own (unfused drop-in composition)
+# ---------------------------------------------------------------------------------------------
+class _LinearScoreFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xs, weight, bias, n):
+        X = _prepare_features(xs)
+        B, L, F = X.shape
+        W = weight.detach().reshape(F).float().contiguous()
+        bvec = None if bias is None else bias.detach().reshape(1).float().contiguous()
+        nn = None if n is None else prepare_n(n, B)
+        scores = torch.empty(B, L, dtype=torch.float32, device=X.device)
+        if B > 0:
+            with _C.device_ctx(X):
+                _C.check(_C.lib().ltr_linear_scores_f32(_C.ptr(X), _C.ptr(W), _C.ptr(bvec), _C.ptr(nn),
+                                                        B, L, F, _C.ptr(scores), _C.stream_of(X)))
+        ctx.save_for_backward(X, nn if nn is not None else torch.empty(0, device=X.device))
+        ctx.has_n = nn is not None
+        ctx.w_shape = weight.shape
+        ctx.has_bias = bias is not None
+        return scores.unsqueeze(-1)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_scores):
+        X, nn = ctx.saved_tensors
+        B, L, F = X.shape
+        g = grad_scores.reshape(B, L).float().contiguous()
+        lib = _C.lib()
+        out = torch.empty(F + 1, dtype=torch.float32, device=X.device)
+        ws_bytes = lib.ltr_linear_grad_workspace_bytes(B, L, F)
+        ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=X.device)
+        with _C.device_ctx(X):
+            _C.check(lib.ltr_linear_grad_f32(_C.ptr(X), _C.ptr(g), _C.ptr(nn) if ctx.has_n else None,
+                                             B, L, F, _C.ptr(out), _C.ptr(ws), ws_bytes, _C.stream_of(X)))
+        return (None, out[:F].reshape(ctx.w_shape), out[F:] if ctx.has_bias else None, None)
+
+
+class LinearScorer(torch.nn.Module):
+    """``torch.nn.Linear(in_features, 1)`` for (B, L, F) feature batches, state_dict-compatible
+    with it, computed by two HBM-streaming kernels instead of rocBLAS' one-column GEMM:
+    ``loss_fn(scorer(xs), ys, n)`` is the reference's user code unchanged.  ``scorer(xs, n)`` also
+    skips the padded documents (score 0).  No gradient flows to ``xs`` (features are data)."""
+
+    def __init__(self, in_features, bias=True):
+        super().__init__()
+        self.in_features = in_features
+        self.weight = torch.nn.Parameter(torch.empty(1, in_features))
+        self.bias = torch.nn.Parameter(torch.empty(1)) if bias else None
+        torch.nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            bound = 1.0 / math.sqrt(in_features)
+            torch.nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, xs, n=None):
+        return _LinearScoreFunction.apply(xs, self.weight, self.bias, n)
 
 
 # ---------------------------------------------------------------------------------------------

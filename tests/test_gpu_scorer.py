@@ -1,0 +1,111 @@
+"""LinearScorer (ltr_linear_scores_f32 / ltr_linear_grad_f32): torch.nn.Linear(F, 1) semantics on
+(B, L, F) batches -- forward and weight gradients against torch in fp32 round-off, padded
+documents skipped, deterministic, and the reference's user code `loss_fn(model(xs), ys, n)`
+end to end against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(8, 16, 5), (64, 128, 136), (7, 33, 137), (3, 1000, 220), (5, 77, 700),
+                                   (2, 9, 1024), (300, 20, 46)])
+def test_forward_and_gradients_match_torch_linear(shape):
+    from pytorchltr_amd.fused import LinearScorer
+    dev = torch.device("cuda")
+    B, L, F = shape
+    s, y, n, X, W, b = synth(B, L, 11 + F, F=F)
+    torch.manual_seed(F)
+    ours = LinearScorer(F).to(dev)
+    ref = torch.nn.Linear(F, 1).to(dev)
+    ref.load_state_dict(ours.state_dict())                       # state_dict compatible
+    Xd = X.to(dev)
+    out = ours(Xd)
+    want = ref(Xd)
+    assert out.shape == want.shape == (B, L, 1)
+    assert torch.allclose(out, want, rtol=1e-5, atol=2e-6 * F ** 0.5)
+    g = torch.randn(B, L, 1, generator=torch.Generator().manual_seed(3)).to(dev)
+    (out * g).sum().backward()
+    (want * g).sum().backward()
+    scale = float(ref.weight.grad.abs().max())
+    assert torch.allclose(ours.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-5 * max(1.0, scale))
+    assert torch.allclose(ours.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-4 * max(1.0, float(ref.bias.grad.abs().max())))
+
+
+def test_padded_documents_are_skipped_and_results_deterministic():
+    from pytorchltr_amd.fused import LinearScorer
+    dev = torch.device("cuda")
+    B, L, F = 50, 64, 136
+    s, y, n, X, W, b = synth(B, L, 5, F=F)
+    n[0], n[1] = 0, L
+    m = LinearScorer(F).to(dev)
+    Xg = X.clone()
+    for q in range(B):
+        Xg[q, int(n[q]):] = float("nan")                         # garbage in the padded slots
+    out = m(Xg.to(dev), n.to(dev))
+    full = m(X.to(dev))
+    valid = (torch.arange(L)[None, :] < n[:, None]).to(dev)
+    assert torch.equal(out.squeeze(-1)[valid], full.squeeze(-1)[valid])
+    assert not out.squeeze(-1)[~valid].any()
+    g = torch.randn(B, L, 1, generator=torch.Generator().manual_seed(1)).to(dev) * valid.unsqueeze(-1)
+    (out * g).sum().backward()
+    first = (m.weight.grad.clone(), m.bias.grad.clone())
+    m.zero_grad()
+    (m(Xg.to(dev), n.to(dev)) * g).sum().backward()
+    assert torch.equal(m.weight.grad, first[0]) and torch.equal(m.bias.grad, first[1])
+    assert bool(torch.isfinite(m.weight.grad).all())
+
+
+@pytest.mark.parametrize("kind", ["hinge", "ndcg2"])
+def test_reference_user_code_against_oracle(kind):
+    """loss_fn(model(xs), ys, n).mean().backward() with model = LinearScorer: loss and dW, db
+    against the fp64 oracle of the same composition."""
+    from oracle import ltr_oracle as O
+    from pytorchltr_amd.fused import LinearScorer
+    from pytorchltr_amd.loss import LambdaNDCGLoss2, PairwiseHingeLoss
+    dev = torch.device("cuda")
+    B, L, F = 24, 100, 136
+    s, y, n, X, W, b = synth(B, L, 77, F=F)
+    m = LinearScorer(F).to(dev)
+    with torch.no_grad():
+        m.weight.copy_(W.reshape(1, F))
+        m.bias.copy_(b)
+    loss_fn = {"hinge": PairwiseHingeLoss, "ndcg2": LambdaNDCGLoss2}[kind]()
+    loss = loss_fn(m(X.to(dev), n.to(dev)), y.to(dev), n.to(dev))
+    loss.mean().backward()
+    want_l, _, want_dW, want_db = O.linear_pairwise(kind, X.numpy(), W.numpy(), float(b), y.numpy(), n.numpy(),
+                                                    np.full(B, 1.0 / B))
+    assert np.allclose(loss.detach().cpu().numpy(), want_l, rtol=2e-5, atol=2e-6)
+    assert np.allclose(m.weight.grad.cpu().numpy().reshape(-1), want_dW, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(want_dW).max()))
+    assert np.allclose(m.bias.grad.cpu().numpy(), want_db, atol=1e-4 * max(1.0, abs(want_db)))
+
+
+def test_fused_linear_loss_takes_the_pieces_for_a_few_long_lists():
+    """FusedLinearLoss on a small batch of long lists runs as scorer + split-query loss + weight
+    gradient kernels; same loss and gradients as the one-kernel fused path (forced via the C ABI
+    step function) and as the oracle."""
+    from oracle import ltr_oracle as O
+    from pytorchltr_amd.fused import FusedLinearLoss, linear_loss_step
+    dev = torch.device("cuda")
+    B, L, F = 20, 700, 64
+    s, y, n, X, W, b = synth(B, L, 9, F=F)
+    m = FusedLinearLoss(F, "logistic").to(dev)
+    assert m._prefer_pieces(B, L)
+    with torch.no_grad():
+        m.weight.copy_(W.reshape(1, F))
+        m.bias.copy_(b)
+    loss, scores = m(X.to(dev), y.to(dev), n.to(dev), return_scores=True)
+    loss.mean().backward()
+    ref_l, ref_dW, ref_db = linear_loss_step(X.to(dev), m.weight, m.bias, y.to(dev), n.to(dev), loss="logistic")
+    assert torch.allclose(loss.detach(), ref_l, rtol=2e-5, atol=1e-5)
+    scale = float(ref_dW.abs().max())
+    assert torch.allclose(m.weight.grad.reshape(-1), ref_dW, rtol=1e-4, atol=2e-5 * max(1.0, scale))
+    assert torch.allclose(m.bias.grad, ref_db, atol=1e-4 * max(1.0, scale))
+    want_l, want_s, _, _ = O.linear_pairwise("logistic", X[:3].numpy(), W.numpy(), float(b), y[:3].numpy(),
+                                             n[:3].numpy(), np.full(3, 1.0 / 3))
+    assert np.allclose(loss.detach().cpu().numpy()[:3], want_l, rtol=2e-5, atol=1e-5)
+    valid = np.arange(L)[None, :] < n[:3].numpy()[:, None]
+    assert np.allclose(scores.cpu().numpy()[:3][valid], want_s[valid], rtol=1e-5, atol=1e-5)
