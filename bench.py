@@ -438,6 +438,16 @@ def main():
             loss_fn(lin(X), relevance, n).mean().backward()
         extra["dropin_linear_plus_loss_module"] = measure(dropin_step)
 
+        # (b2) the same user code with the package's streaming scorer in place of nn.Linear
+        from pytorchltr_amd.fused import LinearScorer
+        scorer = LinearScorer(F).to(dev)
+
+        def dropin_scorer_step():
+            scorer.weight.grad = None
+            scorer.bias.grad = None
+            loss_fn(scorer(X, n), relevance, n).mean().backward()
+        extra["dropin_linearscorer_plus_loss_module"] = measure(dropin_scorer_step)
+
         # (c) loss only (the literal "loss fwd+bwd" on precomputed scores)
         extra["loss_only_module"] = measure(loss_step)
         dsc = torch.empty(B, L, device=dev)
