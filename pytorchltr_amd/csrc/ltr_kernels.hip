@@ -709,13 +709,25 @@ __device__ __forceinline__ float pairwise_core_sym(const QueryLds &q, int nb, in
     const int S = (nt > 0) ? (32 * nt * nt - (32 - dlast)) : 0;
     int u = (w * S) / W;
     const int u1 = ((w + 1) * S) / W;
-    // decode the first unit of this wave into (a, b, j)
-    int a = 0, b = 0, rem = u;
-    while (a < nt) {
-        const int len = (a == b) ? ((a == nt - 1) ? dlast : 32) : 64;
-        if (rem < len) break;
-        rem -= len;
-        if (++b == nt) { ++a; b = a; }
+    // decode the first unit of this wave into (a, b, j): row a of the job triangle holds its
+    // diagonal job (32 steps, dlast in the last row) and 64 steps for every b > a -- walk the rows
+    // (<= nt iterations), then the column is a division (a job-by-job walk cost up to nt^2/2
+    // iterations per wave, a quarter of a split-launch part's whole work at n = 1000)
+    int a = 0, rem = u;
+    while (a < nt - 1) {
+        const int rowlen = 32 + 64 * (nt - 1 - a);
+        if (rem < rowlen) break;
+        rem -= rowlen;
+        ++a;
+    }
+    int b = a;
+    {
+        const int dl = (a == nt - 1) ? dlast : 32;
+        if (rem >= dl && a < nt - 1) {
+            rem -= dl;
+            b = a + 1 + (rem >> 6);
+            rem &= 63;
+        }
     }
     int j = ((a == b) ? 1 : 0) + rem;
 
