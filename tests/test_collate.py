@@ -166,3 +166,27 @@ def test_sampler_sizes_and_global_rng():
     assert UniformSampler(max_list_size=None, generator=g)(rel).shape == (10,)
     assert BalancedRelevanceSampler(max_list_size=None, generator=g)(rel).shape == (10,)
     assert ListSampler(max_list_size=1)(torch.tensor([0])).tolist() == [0]
+
+
+@pytest.mark.gpu
+def test_sort_by_length_reorders_whole_queries():
+    """collate(sort_by_length=True): same queries, ordered by decreasing document count (stable),
+    every row still the right query."""
+    from pytorchltr_amd.datasets import RaggedQueries
+    g = torch.Generator().manual_seed(5)
+    counts = torch.randint(1, 30, (12,), generator=g)
+    offsets = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(counts, 0)])
+    xs = torch.randn(int(offsets[-1]), 4, generator=g)
+    ys = torch.randint(0, 5, (int(offsets[-1]),), generator=g)
+    ds = RaggedQueries(xs, ys, offsets, qids=torch.arange(100, 112), device="cuda")
+    picked = [3, 7, 0, 11, 5, 2]
+    plain = ds.collate(picked)
+    srt = ds.collate(picked, sort_by_length=True)
+    n_sorted = srt.n.cpu()
+    assert bool((n_sorted[:-1] >= n_sorted[1:]).all())
+    assert sorted(srt.qid.cpu().tolist()) == sorted(plain.qid.cpu().tolist())
+    for row, qid in enumerate(srt.qid.cpu().tolist()):
+        src = plain.qid.cpu().tolist().index(qid)
+        k = int(srt.n[row])
+        assert torch.equal(srt.features[row, :k], plain.features[src, :k])
+        assert torch.equal(srt.relevance[row, :k], plain.relevance[src, :k])
