@@ -1,10 +1,9 @@
 """Data layer pieces adjacent to the hot path: list samplers, the
 device-side collate/padding of ragged query storage into the padded (B, L, F) batch the loss
 and metric kernels consume, and the SVMrank text parser that fills that storage."""
-from pytorchltr_amd.datasets.list_sampler import ListSampler  # noqa: F401
-from pytorchltr_amd.datasets.list_sampler import UniformSampler  # noqa: F401
-from pytorchltr_amd.datasets.list_sampler import BalancedRelevanceSampler  # noqa: F401
-from pytorchltr_amd.datasets.ragged import RaggedQueries  # noqa: F401
-from pytorchltr_amd.datasets.ragged import SVMRankBatch  # noqa: F401
-from pytorchltr_amd.datasets.svmrank import load_svmrank  # noqa: F401
-from pytorchltr_amd.datasets.svmrank import parse_svmrank_file  # noqa: F401
+from pytorchltr_amd.datasets.list_sampler import BalancedRelevanceSampler, ListSampler, UniformSampler
+from pytorchltr_amd.datasets.ragged import RaggedQueries, SVMRankBatch
+from pytorchltr_amd.datasets.svmrank import load_svmrank, parse_svmrank_file
+
+__all__ = ["ListSampler", "UniformSampler", "BalancedRelevanceSampler", "RaggedQueries",
+           "SVMRankBatch", "load_svmrank", "parse_svmrank_file"]

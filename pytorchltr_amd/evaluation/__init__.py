@@ -1,5 +1,7 @@
-"""Ranking metrics -- same names as pytorchltr/evaluation/__init__.py:1-4."""
-from pytorchltr_amd.evaluation.arp import arp  # noqa: F401
-from pytorchltr_amd.evaluation.dcg import ndcg  # noqa: F401
-from pytorchltr_amd.evaluation.dcg import dcg  # noqa: F401
-from pytorchltr_amd.evaluation.trec import generate_pytrec_eval  # noqa: F401
+"""Ranking metrics and the pytrec_eval export: the names pytorchltr/evaluation/__init__.py:1-4
+exports, same signatures."""
+from pytorchltr_amd.evaluation.arp import arp
+from pytorchltr_amd.evaluation.dcg import dcg, ndcg
+from pytorchltr_amd.evaluation.trec import generate_pytrec_eval
+
+__all__ = ["arp", "dcg", "ndcg", "generate_pytrec_eval"]

@@ -1,8 +1,19 @@
-"""Ranking losses -- same names as pytorchltr/loss/__init__.py:1-7."""
-from pytorchltr_amd.loss.pairwise_additive import PairwiseHingeLoss  # noqa: F401
-from pytorchltr_amd.loss.pairwise_additive import PairwiseDCGHingeLoss  # noqa: F401
-from pytorchltr_amd.loss.pairwise_additive import PairwiseLogisticLoss  # noqa: F401
-from pytorchltr_amd.loss.pairwise_lambda import LambdaARPLoss1  # noqa: F401
-from pytorchltr_amd.loss.pairwise_lambda import LambdaARPLoss2  # noqa: F401
-from pytorchltr_amd.loss.pairwise_lambda import LambdaNDCGLoss1  # noqa: F401
-from pytorchltr_amd.loss.pairwise_lambda import LambdaNDCGLoss2  # noqa: F401
+"""Ranking losses.  The seven classes the reference exports (pytorchltr/loss/__init__.py:1-7),
+same constructor arguments and ``forward(scores, relevance, n)``, computed by the HIP kernels
+behind ``ltr_pairwise_loss_f32``."""
+from pytorchltr_amd.loss.pairwise_additive import (
+    PairwiseDCGHingeLoss,
+    PairwiseHingeLoss,
+    PairwiseLogisticLoss,
+)
+from pytorchltr_amd.loss.pairwise_lambda import (
+    LambdaARPLoss1,
+    LambdaARPLoss2,
+    LambdaNDCGLoss1,
+    LambdaNDCGLoss2,
+)
+
+__all__ = [
+    "PairwiseHingeLoss", "PairwiseDCGHingeLoss", "PairwiseLogisticLoss",
+    "LambdaARPLoss1", "LambdaARPLoss2", "LambdaNDCGLoss1", "LambdaNDCGLoss2",
+]

@@ -1,6 +1,11 @@
-"""Tensor helpers -- same names as pytorchltr/utils/__init__.py:1-5."""
-from pytorchltr_amd.utils.tensor_operations import mask_padded_values  # noqa: F401
-from pytorchltr_amd.utils.tensor_operations import tiebreak_argsort  # noqa: F401
-from pytorchltr_amd.utils.tensor_operations import rank_by_score  # noqa: F401
-from pytorchltr_amd.utils.tensor_operations import batch_pairs  # noqa: F401
-from pytorchltr_amd.utils.tensor_operations import rank_by_plackettluce  # noqa: F401
+"""Tensor helpers: the five names pytorchltr/utils/__init__.py:1-5 exports, same signatures."""
+from pytorchltr_amd.utils.tensor_operations import (
+    batch_pairs,
+    mask_padded_values,
+    rank_by_plackettluce,
+    rank_by_score,
+    tiebreak_argsort,
+)
+
+__all__ = ["mask_padded_values", "tiebreak_argsort", "rank_by_score", "rank_by_plackettluce",
+           "batch_pairs"]
