@@ -939,11 +939,20 @@ __host__ __device__ inline int split_parts_for(int nb, int nsplit, int waves)
 
 template <int KIND>
 __global__ void __launch_bounds__(1024)
-pairwise_loss_split_kernel(LossParams p, int nsplit, float *ws)
+pairwise_loss_split_kernel(LossParams p, int nsplit, int part_major, float *ws)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.x / nsplit;
-    const int part = blockIdx.x - b * nsplit;
+    // Query-major by default.  When all the parts fit the chip in one go (part_major), the parts of
+    // one query are launched B blocks apart instead: with B % 8 == 0 they land on one XCD and share
+    // its L2 for the staged rows (measured: 27.9 -> 24.0 us at 32 x 1000, hinge).
+    int b, part;
+    if (part_major) {
+        part = blockIdx.x / p.B;
+        b = blockIdx.x - part * p.B;
+    } else {
+        b = blockIdx.x / nsplit;
+        part = blockIdx.x - b * nsplit;
+    }
     const int L = p.L;
     const int tid = threadIdx.x;
     const int T = blockDim.x;
@@ -1525,8 +1534,9 @@ static int launch_loss_split(const LossParams &p, int nsplit, float *ws, hipStre
     const int waves = kSplitWaves;
     const size_t lds = loss_lds_bytes(KIND, (p.L + 63) & ~63, waves);
     LTR_ENSURE_LDS((pairwise_loss_split_kernel<KIND>), lds);
+    const int part_major = (long long)p.B * nsplit <= device_cu_count() ? 1 : 0;
     hipLaunchKernelGGL((pairwise_loss_split_kernel<KIND>), dim3((unsigned)(p.B * nsplit)), dim3(64 * waves),
-                       lds, stream, p, nsplit, ws);
+                       lds, stream, p, nsplit, part_major, ws);
     hipLaunchKernelGGL((pairwise_loss_finish_kernel<KIND>), dim3((unsigned)p.B), dim3(256), 0, stream, p,
                        nsplit, waves, (const float *)ws);
     return (int)hipGetLastError();
