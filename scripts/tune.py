@@ -99,10 +99,11 @@ def main():
             print("  trace (cycles): kernel span %.0f | per-query mean " % (t[:, 5].max() - t0) +
                   " ".join("%s %.0f" % (nm, d[:, i].mean()) for i, nm in enumerate(names)) +
                   " | total/query mean %.0f max %.0f" % ((t[:, 5] - t[:, 0]).mean(), (t[:, 5] - t[:, 0]).max()))
-            nbv = t[:, 6]
+            print("  entry -> first stamp (scheduling): mean %.0f max %.0f cycles" % ((t[:, 0] - t[:, 6]).mean(), (t[:, 0] - t[:, 6]).max()))
+            nbv = n.cpu().double()
             big = nbv > 100
             print("  queries with n>100: " + " ".join("%s %.0f" % (nm, d[big, i].mean()) for i, nm in enumerate(names)))
-            blk = t[:, 7].long()
+            blk = torch.arange(B)
             per_block_end = torch.zeros(int(blk.max()) + 1).double()
             per_block_cnt = torch.zeros(int(blk.max()) + 1)
             for i in range(B):
