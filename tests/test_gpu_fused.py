@@ -186,3 +186,43 @@ def test_sgd_learning_improves_arp():
     with torch.no_grad():
         end = float(arp(model(X), y, n).mean())
     assert end - start <= -0.40
+
+
+@pytest.mark.parametrize("B", [289, 300, 517, 1000, 1023, 1024])
+@pytest.mark.parametrize("lists", ["ragged", "full", "empty_but_one", "two_lengths", "steps_of_16"])
+def test_list_length_scheduling_visits_every_query_once(B, lists):
+    """With 1.125 x #CUs < B <= 4 x #CUs the register-tile kernel maps block ids to queries through
+    the in-kernel list-length order.  B workgroups write B loss entries: every entry written
+    (no NaN left from the prefill) means the mapping is a bijection; the values must not depend on
+    it (compared with the unscheduled general kernel, which the score output selects)."""
+    from pytorchltr_amd import _C
+    from pytorchltr_amd.fused import linear_loss_step
+    dev = _dev()
+    L, F = 128, 136
+    s, y, n, X, W, b = synth(B, L, 77, F=F)
+    if lists == "full":
+        n = torch.full_like(n, L)
+    elif lists == "empty_but_one":
+        n = torch.zeros_like(n)
+        n[B // 2] = 3
+    elif lists == "two_lengths":
+        n = torch.where(torch.arange(B) % 3 == 0, torch.full_like(n, L), torch.full_like(n, 2))
+    elif lists == "steps_of_16":
+        n = (n // 16) * 16
+    X, W, b, y, n = X.to(dev), W.to(dev), b.to(dev), y.to(dev), n.to(dev)
+    lib = _C.lib()
+    loss = torch.full((B,), float("nan"), device=dev)
+    part = torch.full((lib.ltr_linear_workspace_bytes(B, L, F) // 4,), float("nan"), device=dev)
+    _C.check(lib.ltr_linear_partials_f32(0, 1.0, X.data_ptr(), W.data_ptr(), b.data_ptr(), y.data_ptr(),
+                                         _C.label_dtype(y), n.data_ptr(), B, L, F, loss.data_ptr(), None,
+                                         part.data_ptr(), _C.stream_of(X)))
+    torch.cuda.synchronize()
+    assert not torch.isnan(loss).any()
+    assert not torch.isnan(part[:B * (F + 1)]).any()
+    want, dW_want, db_want, _ = linear_loss_step(X, W, b, y, n, loss="hinge", return_scores=True)
+    assert torch.allclose(loss, want, rtol=2e-5, atol=1e-5)
+    got, dW, db = linear_loss_step(X, W, b, y, n, loss="hinge")
+    assert torch.equal(got, loss)
+    # two fp32 kernels with different summation orders: twice the 2e-5 bound each holds vs fp64
+    tol = 5e-5 * max(1.0, float(dW_want.abs().max()))
+    assert float((dW - dW_want).abs().max()) < tol and abs(float(db - db_want)) < tol
