@@ -89,6 +89,60 @@ __device__ __forceinline__ int clamp_n(int64_t n, int L)
     return n < 0 ? 0 : (n > (int64_t)L ? L : (int)n);
 }
 
+// Which query a workgroup takes (one workgroup per query: the fused scorer+loss kernels and the
+// loss kernel).  The hardware starts block ids in
+// order, round-robin over the 8 XCDs and, inside an XCD, over its 32 CUs (a CU hosts ids i, i+256,
+// i+512, ...), and a launch of a few workgroups per CU lasts as long as its most loaded CU / its
+// last workgroup.  Measured at C2/C3 shapes (n ~ U[1,128], B = 1024; profiles/README.md): batch in
+// random order 13.5-14.0 us (hinge) / 23.7 (LambdaNDCG2) / 18.2 (logistic); the same batch sorted
+// by n descending 12.2 / 20.0 / 15.3 -- long lists first, and every CU gets one list of each
+// quartile.  A full sort of n[] inside every workgroup costs more than that (tried: counting
+// sort, 8 000-15 000 cycles), so the order is approximated with 64-query samples: the batch is cut
+// into G = ceil(B/64) interleaved groups (group g = chunks of 8 consecutive ids, G chunks apart),
+// each group is ranked by n descending, and block id `pos` -- member number m of its group -- takes
+// the group's m-th longest list.  Early ids get every group's longest lists, late ids the shortest:
+// 12.1 / 20.3 / 15.5 us with the permutation applied on the host.  ONE wave finds the query
+// without LDS traffic: one n per lane (8 x 64-byte segments), a radix select over the bits of n
+// with ballots (uniform control flow, ~100 instructions), ties by lane order.  A bijection inside
+// each group and a pure function of n[]; every output is indexed by the query, so results do not
+// depend on it.
+#ifndef LTR_SCHED_MAX_PER_CU
+#define LTR_SCHED_MAX_PER_CU 4        // register-tile kernel (B = 8 x #CUs: 22.1 -> 23.9 us with it)
+#endif
+#ifndef LTR_LOSS_SCHED_MAX_PER_CU
+#define LTR_LOSS_SCHED_MAX_PER_CU 16   // loss kernel, general fused kernel
+#endif
+__device__ __forceinline__ int sched_query_sampled(const int64_t *__restrict__ n, int B, int L, int G, int tid,
+                                                   int &nb_out)
+{
+    __shared__ int s_sel[2];
+    if (tid < 64) {
+        const int lane = tid;
+        const int pos = (int)blockIdx.x;
+        const int u = pos >> 3;
+        const int jp = u / G;
+        const int gam = u - jp * G;
+        int rho = jp * 8 + (pos & 7);                            // this block's member number
+        const int id = ((lane >> 3) * G + gam) * 8 + (lane & 7); // member `lane` of the group
+        unsigned long long cand = __ballot(id < B);              // a prefix of the lanes (ids grow with lane)
+        const int key = clamp_n(n[min(id, B - 1)], L);
+        // (all lists equally long, e.g. full lists: cand stays the whole group and rho the lane)
+        const bool flat = __ballot(key != __builtin_amdgcn_readfirstlane(key)) == 0ull;
+        for (int bt = flat ? -1 : 31 - __builtin_clz(L); bt >= 0; --bt) {   // descending n: set bits first
+            const unsigned long long m = __ballot(((key >> bt) & 1) != 0) & cand;
+            const int c = __popcll(m);
+            if (rho < c) cand = m;
+            else { rho -= c; cand &= ~m; }
+        }
+        // cand = the lanes holding the selected n; the rho-th of them in lane order takes the block
+        const int below = __popcll(cand & ((1ull << lane) - 1ull));
+        if ((((cand >> lane) & 1ull) != 0ull) && below == rho) { s_sel[0] = id; s_sel[1] = key; }
+    }
+    __syncthreads();
+    nb_out = __builtin_amdgcn_readfirstlane(s_sel[1]);           // saves the dependent n[b] load
+    return __builtin_amdgcn_readfirstlane(s_sel[0]);
+}
+
 // Cross-lane adds on the DPP path (no LDS round trip; HIP's __shfl_* lower to ds_bpermute).
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_move(float v)
@@ -396,6 +450,7 @@ struct LossParams {
     float sigma;
     int rel_dtype;
     int msplit;
+    int sched;          // > 0: number of 64-query sample groups of the list-length scheduling
 };
 
 // LDS carve (bytes), L4 = L rounded up to 4:
@@ -845,15 +900,20 @@ __global__ void __launch_bounds__(1024)
 pairwise_loss_kernel(LossParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.x;
     const int L = p.L;
     const int tid = threadIdx.x;
     const int T = blockDim.x;
+    int b, nb;
+    if (p.sched) {
+        b = sched_query_sampled(p.n, p.B, L, p.sched, tid, nb);
+    } else {
+        b = (int)blockIdx.x;
+        nb = clamp_n(p.n[b], L);
+    }
     constexpr bool kSym = (DPT == 0);              // DPT == 0 selects the symmetric pair pass
     // LDS row stride: list_len rounded to 4 (both-ends pass) or to whole 64-wide tiles (symmetric)
     const int L4 = kSym ? ((L + 63) & ~63) : ((L + 3) & ~3);
     const int msplit = kSym ? (T >> 6) : p.msplit; // gradient slices: per wave / per m-slice
-    const int nb = clamp_n(p.n[b], L);
     const QueryLds q = carve_query_lds<KIND>(smem, L4, msplit);
 #if defined(LTR_DEBUG_STOP) && LTR_DEBUG_STOP == 0
     if (p.B >= 0) return;                        // tuning: launch + dispatch floor
@@ -1398,7 +1458,9 @@ __global__ void collate_pad_kernel(const V *__restrict__ xs, const int64_t *__re
 // ---------------------------------------------------------------------------------
 // host side: launch-shape heuristic and dispatch
 // ---------------------------------------------------------------------------------
-constexpr size_t kLdsBudget = 160 * 1024;
+// (64 bytes short of the CU's 160 KB: kernels that use sched_query_sampled carry 8 bytes of static
+// LDS, and static + dynamic must fit together)
+constexpr size_t kLdsBudget = 160 * 1024 - 64;
 // Raise a kernel's dynamic-LDS limit above the 64 KiB default once per device (the attribute is
 // sticky), so steady-state launches -- including hipGraph capture -- issue no extra API calls.
 constexpr int kMaxDevices = 64;
@@ -1511,6 +1573,30 @@ inline int device_cu_count()
         cached[dev] = v;
     }
     return cached[dev];
+}
+
+// Number of sample groups for sched_query_sampled, or 0 = plain order: worth it with more than one
+// workgroup per CU and up to `max_per_cu` of them (beyond that the order stops mattering).
+inline int sched_groups(int B, int max_per_cu)
+{
+#ifdef LTR_NO_SCHED
+    (void)B; (void)max_per_cu;
+    return 0;
+#else
+    const int cus = device_cu_count();
+    return (B > cus + cus / 8 && (long long)B <= (long long)max_per_cu * cus) ? (B + 63) / 64 : 0;
+#endif
+}
+
+// The loss kernel and the general fused kernel: the pass costs ~0.3 us per launch, which short
+// lists do not win back (L = 64: 5.0 -> 5.2 us at B = 1024); lists of 128 need a full chip
+// (B >= 4 x #CUs: hinge 7.0 -> 6.7, LambdaNDCG2 15.0 -> 13.2), longer ones always gain (L = 512,
+// B = 1024: hinge 37 -> 28 us, logistic 75 -> 55, LambdaNDCG2 148 -> 120; profiles/README.md).
+inline int sched_groups_for_lists(int B, int L)
+{
+    if (L <= 64) return 0;
+    if (L < 256 && B < 4 * device_cu_count()) return 0;
+    return sched_groups(B, LTR_LOSS_SCHED_MAX_PER_CU);
 }
 
 // How many workgroups share a query in the split launch (1 = use the one-kernel path): long lists
@@ -1640,6 +1726,7 @@ int ltr_pairwise_loss_f32_cfg(int kind, float sigma, const float *scores, const 
     LossParams p;
     p.scores = scores; p.rel = rel; p.n = n; p.loss = loss; p.dscores = dscores;
     p.B = B; p.L = L; p.sigma = sigma; p.rel_dtype = rel_dtype; p.msplit = msplit;
+    p.sched = sched_groups_for_lists(B, L);
     LaunchShape s{owners, dpt, msplit};
     return launch_loss(kind, p, s, (hipStream_t)stream);
 }
@@ -1679,6 +1766,7 @@ int ltr_pairwise_loss_ws_f32(int kind, float sigma, const float *scores, const v
     LossParams p;
     p.scores = scores; p.rel = rel; p.n = n; p.loss = loss; p.dscores = dscores;
     p.B = B; p.L = L; p.sigma = sigma; p.rel_dtype = rel_dtype; p.msplit = kSplitWaves;
+    p.sched = 0;
     float *ws = (float *)workspace;
     hipStream_t st = (hipStream_t)stream;
     switch (kind) {

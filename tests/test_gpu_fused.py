@@ -226,3 +226,12 @@ def test_list_length_scheduling_visits_every_query_once(B, lists):
     # two fp32 kernels with different summation orders: twice the 2e-5 bound each holds vs fp64
     tol = 5e-5 * max(1.0, float(dW_want.abs().max()))
     assert float((dW - dW_want).abs().max()) < tol and abs(float(db - db_want)) < tol
+
+
+@pytest.mark.parametrize("kind", ["hinge", "logistic", "ndcg1"])
+def test_list_length_scheduling_in_the_general_fused_kernel(kind):
+    """The general (re-read) fused kernel under the list-length order: long lists with more than
+    one workgroup per CU, and F % 4 != 0 at B >= 4 x #CUs."""
+    _check(kind, 300, 300, 64, 9)
+    _check(kind, 1100, 128, 6, 10)
+    _check(kind, 310, 260, 12, 11, full=True)

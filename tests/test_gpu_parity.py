@@ -429,3 +429,34 @@ def test_hipgraph_capture_and_side_stream():
         _check_grad(sc.grad.cpu().numpy() * 64.0, want_g, "graph replay")
         assert np.allclose(static_metric.cpu().numpy(), O.ndcg(s2.numpy(), y.numpy(), n.numpy(), k=10),
                            rtol=2e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(300, 256), (1100, 128), (1030, 300), (2048, 130)])
+@pytest.mark.parametrize("lists", ["ragged", "full", "two_lengths", "mostly_empty"])
+def test_list_length_scheduling_in_the_loss_kernel(shape, lists):
+    """Shapes where the loss kernel maps block ids to queries through the in-kernel list-length
+    order (more than one workgroup per CU, lists of 128+): every query still gets its own loss and
+    gradient row (NaN prefill), equal to the oracle's."""
+    from pytorchltr_amd import _C
+    B, L = shape
+    dev = _dev()
+    s, y, n = synth(B, L, 4242)[:3]
+    if lists == "full":
+        n = torch.full_like(n, L)
+    elif lists == "two_lengths":
+        n = torch.where(torch.arange(B) % 5 == 0, torch.full_like(n, L), torch.full_like(n, 3))
+    elif lists == "mostly_empty":
+        n = torch.where(torch.arange(B) % 7 == 0, n, torch.zeros_like(n))
+    sd, yd, nd = s.to(dev), y.to(dev), n.to(dev)
+    lib = _C.lib()
+    for kind in ("hinge", "logistic", "ndcg2"):
+        loss = torch.full((B,), float("nan"), device=dev)
+        ds = torch.full((B, L), float("nan"), device=dev)
+        _C.check(lib.ltr_pairwise_loss_f32(_C.__dict__[kind.upper()], 1.0, sd.data_ptr(), yd.data_ptr(),
+                                           _C.label_dtype(yd), nd.data_ptr(), B, L, loss.data_ptr(),
+                                           ds.data_ptr(), _C.stream_of(sd)))
+        torch.cuda.synchronize()
+        assert not torch.isnan(loss).any() and not torch.isnan(ds).any(), kind
+        want_l, want_g = O.pairwise_loss(kind, s.numpy(), y.numpy(), n.numpy(), sigma=1.0)
+        _check_loss(loss.cpu().numpy(), want_l, L, "%s %s %s" % (shape, lists, kind))
+        _check_grad(ds.cpu().numpy(), want_g, "%s %s %s" % (shape, lists, kind), exact=(kind == "hinge"))
