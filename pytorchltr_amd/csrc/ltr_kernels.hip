@@ -113,12 +113,11 @@ __device__ __forceinline__ int clamp_n(int64_t n, int L)
 #define LTR_LOSS_SCHED_MAX_PER_CU 16   // loss kernel, general fused kernel
 #endif
 __device__ __forceinline__ int sched_query_sampled(const int64_t *__restrict__ n, int B, int L, int G, int tid,
-                                                   int &nb_out)
+                                                   int &nb_out, int pos)
 {
     __shared__ int s_sel[2];
     if (tid < 64) {
         const int lane = tid;
-        const int pos = (int)blockIdx.x;
         const int u = pos >> 3;
         const int jp = u / G;
         const int gam = u - jp * G;
@@ -905,7 +904,7 @@ pairwise_loss_kernel(LossParams p)
     const int T = blockDim.x;
     int b, nb;
     if (p.sched) {
-        b = sched_query_sampled(p.n, p.B, L, p.sched, tid, nb);
+        b = sched_query_sampled(p.n, p.B, L, p.sched, tid, nb, (int)blockIdx.x);
     } else {
         b = (int)blockIdx.x;
         nb = clamp_n(p.n[b], L);
@@ -1005,20 +1004,29 @@ pairwise_loss_split_kernel(LossParams p, int nsplit, int part_major, float *ws)
     // Query-major by default.  When all the parts fit the chip in one go (part_major), the parts of
     // one query are launched B blocks apart instead: with B % 8 == 0 they land on one XCD and share
     // its L2 for the staged rows (measured: 27.9 -> 24.0 us at 32 x 1000, hinge).
-    int b, part;
-    if (part_major) {
-        part = blockIdx.x / p.B;
-        b = blockIdx.x - part * p.B;
-    } else {
-        b = blockIdx.x / nsplit;
-        part = blockIdx.x - b * nsplit;
-    }
+    // Otherwise query-major over the list-length order (sched_query_sampled): block ids 8r .. 8r+7
+    // are the parts of the query of rank r, so a CU (ids 256 apart) hosts parts of queries whose
+    // ranks are 32 apart -- one of every length class -- instead of 8 random queries.
     const int L = p.L;
     const int tid = threadIdx.x;
     const int T = blockDim.x;
+    int b, part, nb;
+    if (part_major) {
+        part = blockIdx.x / p.B;
+        b = blockIdx.x - part * p.B;
+        nb = clamp_n(p.n[b], L);
+    } else {
+        const int qpos = blockIdx.x / nsplit;
+        part = blockIdx.x - qpos * nsplit;
+        if (p.sched) {
+            b = sched_query_sampled(p.n, p.B, L, p.sched, tid, nb, qpos);
+        } else {
+            b = qpos;
+            nb = clamp_n(p.n[b], L);
+        }
+    }
     const int L4 = (L + 63) & ~63;
     const int msplit = T >> 6;
-    const int nb = clamp_n(p.n[b], L);
     const int parts = split_parts_for(nb, nsplit, msplit);
     if (part >= parts) return;                           // uniform: nothing for this workgroup
     const QueryLds q = carve_query_lds<KIND>(smem, L4, msplit);
@@ -1054,6 +1062,8 @@ template <int KIND>
 __global__ void __launch_bounds__(256)
 pairwise_loss_finish_kernel(LossParams p, int nsplit, int waves, const float *ws)
 {
+    // grid (B, ceil(L / 256)): one gradient entry per thread, the parts' slices read as independent
+    // loads (one workgroup per query walked them one after the other: 9.8 us at C4, now ~3)
     const int b = blockIdx.x;
     const int L = p.L;
     const int nb = clamp_n(p.n[b], L);
@@ -1069,17 +1079,21 @@ pairwise_loss_finish_kernel(LossParams p, int nsplit, int waves, const float *ws
     } else if (KIND != LTR_HINGE) {
         gscale = p.sigma / kLn2;
     }
-    if (threadIdx.x == 0) p.loss[b] = total;
+    if (threadIdx.x == 0 && blockIdx.y == 0) p.loss[b] = total;
     if (p.dscores != nullptr) {
         const float *wg = ws + (size_t)p.B * nsplit + (size_t)b * nsplit * L;
-        float *out = p.dscores + (size_t)b * L;
-        for (int k = threadIdx.x; k < L; k += blockDim.x) {
+        const int k = blockIdx.y * blockDim.x + threadIdx.x;
+        if (k < L) {
             float g = 0.f;
             if (k < nb) {
-                for (int s = 0; s < parts; ++s) g += wg[(size_t)s * L + k];
+                float v[LTR_SPLIT_MAX];
+#pragma unroll
+                for (int s = 0; s < LTR_SPLIT_MAX; ++s) v[s] = (s < parts) ? wg[(size_t)s * L + k] : 0.f;
+#pragma unroll
+                for (int s = 0; s < LTR_SPLIT_MAX; ++s) g += v[s];   // fixed order; the extra terms are +0
                 g *= gscale;
             }
-            out[k] = g;
+            p.dscores[(size_t)b * L + k] = g;
         }
     }
 }
@@ -1608,7 +1622,10 @@ static int choose_loss_splits(int kind, int B, int L)
     // the NDCG kinds would repeat their two rankings in every part: they keep the plain path
     if (kind == LTR_NDCG1 || kind == LTR_NDCG2) return 1;
     const int cus = device_cu_count();
-    if (2 * B > 3 * cus) return 1;       // measured: no gain once the batch has > 1.5 queries per CU
+    // measured (hinge / logistic, us, plain kernel with the list-length order -> split launch):
+    // 384 x 1000: 35/66 either way; 512 x 1000: 58/135 -> 43/90; 768 x 1000: 71/163 -> 69/149;
+    // 1024 x 1000: 72/175 -> 78/180; 512 x 512: 18/37 -> 20/35; 768 x 300: 14/21 -> 17/27
+    if (2 * B > 3 * cus && !(B <= 2 * cus && L > 640)) return 1;
     int s = (LTR_SPLIT_MAX * cus) / (B > 0 ? B : 1);
     if (s > LTR_SPLIT_MAX) s = LTR_SPLIT_MAX;
     return s < 2 ? 1 : s;
@@ -1623,8 +1640,8 @@ static int launch_loss_split(const LossParams &p, int nsplit, float *ws, hipStre
     const int part_major = (long long)p.B * nsplit <= device_cu_count() ? 1 : 0;
     hipLaunchKernelGGL((pairwise_loss_split_kernel<KIND>), dim3((unsigned)(p.B * nsplit)), dim3(64 * waves),
                        lds, stream, p, nsplit, part_major, ws);
-    hipLaunchKernelGGL((pairwise_loss_finish_kernel<KIND>), dim3((unsigned)p.B), dim3(256), 0, stream, p,
-                       nsplit, waves, (const float *)ws);
+    hipLaunchKernelGGL((pairwise_loss_finish_kernel<KIND>), dim3((unsigned)p.B, (unsigned)((p.L + 255) / 256)),
+                       dim3(256), 0, stream, p, nsplit, waves, (const float *)ws);
     return (int)hipGetLastError();
 }
 
@@ -1766,7 +1783,11 @@ int ltr_pairwise_loss_ws_f32(int kind, float sigma, const float *scores, const v
     LossParams p;
     p.scores = scores; p.rel = rel; p.n = n; p.loss = loss; p.dscores = dscores;
     p.B = B; p.L = L; p.sigma = sigma; p.rel_dtype = rel_dtype; p.msplit = kSplitWaves;
+#ifdef LTR_NO_SPLIT_SCHED
     p.sched = 0;
+#else
+    p.sched = (B >= 16) ? (B + 63) / 64 : 0;            // (ignored by the part-major order)
+#endif
     float *ws = (float *)workspace;
     hipStream_t st = (hipStream_t)stream;
     switch (kind) {
