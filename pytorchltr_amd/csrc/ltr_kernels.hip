@@ -1619,13 +1619,14 @@ constexpr int kSplitWaves = LTR_SPLIT_WAVES;   // waves per part: small workgrou
 static int choose_loss_splits(int kind, int B, int L)
 {
     if (L <= 256 || L > kSymMaxLen) return 1;
-    // the NDCG kinds would repeat their two rankings in every part: they keep the plain path
-    if (kind == LTR_NDCG1 || kind == LTR_NDCG2) return 1;
     const int cus = device_cu_count();
     // measured (hinge / logistic, us, plain kernel with the list-length order -> split launch):
     // 384 x 1000: 35/66 either way; 512 x 1000: 58/135 -> 43/90; 768 x 1000: 71/163 -> 69/149;
     // 1024 x 1000: 72/175 -> 78/180; 512 x 512: 18/37 -> 20/35; 768 x 300: 14/21 -> 17/27
-    if (2 * B > 3 * cus && !(B <= 2 * cus && L > 640)) return 1;
+    // The NDCG kinds repeat their two rankings in every part (32 x 1000: 130 -> 61 us all the same,
+    // 128 x 600: 65 -> 50, 256 x 1000: 132 -> 118 / 146 -> 143); at 512 x 1000 that loses (161 -> 178)
+    const bool ndcg = (kind == LTR_NDCG1 || kind == LTR_NDCG2);
+    if (2 * B > 3 * cus && !(!ndcg && B <= 2 * cus && L > 640)) return 1;
     int s = (LTR_SPLIT_MAX * cus) / (B > 0 ? B : 1);
     if (s > LTR_SPLIT_MAX) s = LTR_SPLIT_MAX;
     return s < 2 ? 1 : s;
