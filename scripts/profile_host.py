@@ -30,7 +30,25 @@ def metric():
     ndcg(scores, y, n, k=10)
 
 
-for name, fn in (("loss step", step), ("ndcg@10", metric)):
+from pytorchltr_amd.fused import FusedLinearLoss, LinearScorer  # noqa: E402
+fused = FusedLinearLoss(136, "hinge").to(dev)
+scorer = LinearScorer(136).to(dev)
+
+
+def fused_step():
+    fused.zero_grad(set_to_none=True)
+    fused(X, y, n).mean().backward()
+
+
+def scorer_step():
+    scorer.zero_grad(set_to_none=True)
+    loss_fn(scorer(X, n), y, n).mean().backward()
+
+
+CASES = {"loss": ("loss step", step), "ndcg": ("ndcg@10", metric), "fused": ("FusedLinearLoss step", fused_step),
+         "scorer": ("LinearScorer + loss step", scorer_step)}
+want = sys.argv[1:] or ["loss", "ndcg"]
+for name, fn in (CASES[w] for w in want):
     for _ in range(200):
         fn()
     torch.cuda.synchronize()
@@ -46,4 +64,4 @@ for name, fn in (("loss step", step), ("ndcg@10", metric)):
     pr.disable()
     torch.cuda.synchronize()
     st = pstats.Stats(pr)
-    st.sort_stats("tottime").print_stats(14)
+    st.sort_stats("tottime").print_stats(22)
