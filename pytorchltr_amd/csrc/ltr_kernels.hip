@@ -996,9 +996,47 @@ __host__ __device__ inline int split_parts_for(int nb, int nsplit, int waves)
     return e < nsplit ? e : nsplit;
 }
 
+// Rankings of the NDCG kinds for the split-query launch, once per query (the parts of a query
+// would each repeat two 1024-element sorts): one 1024-thread workgroup stages the row, runs
+// prepare_ndcg and leaves per document (a_k, 0) for LambdaNDCG1 or (G_k / maxDCG, rank_k) for
+// LambdaNDCG2 in the workspace.
 template <int KIND>
 __global__ void __launch_bounds__(1024)
-pairwise_loss_split_kernel(LossParams p, int nsplit, int part_major, float *ws)
+ndcg_prepare_kernel(LossParams p, float2 *prep)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x;
+    const int L = p.L;
+    const int tid = threadIdx.x;
+    const int T = blockDim.x;
+    const int L4 = (L + 63) & ~63;
+    const int nb = clamp_n(p.n[b], L);
+    const QueryLds q = carve_query_lds<KIND>(smem, L4, T >> 6);
+    const size_t row = (size_t)b * L;
+    stage_rows(q.sy, p.scores + row, p.rel, p.rel_dtype, row, L, nb, tid, T);
+    for (int m = tid; m < 2 * L4; m += T) q.rank_s[m] = 0;
+    __syncthreads();
+    int owners = 64;
+    while (owners < L4 && owners < T) owners *= 2;
+    const int ms = T / owners;
+    const int mlen = (nb + ms - 1) / ms;
+    const int m0 = __builtin_amdgcn_readfirstlane(min(nb, (tid / owners) * mlen));
+    const int m1 = __builtin_amdgcn_readfirstlane(min(nb, m0 + mlen));
+    prepare_ndcg<KIND, 1>(q, nb, owners, tid % owners, m0, m1, ms > 1);
+    float2 *out = prep + row;
+    for (int k = tid; k < nb; k += T) {
+        if (KIND == LTR_NDCG1) {
+            out[k] = make_float2(q.sy[k].y, 0.f);
+        } else {
+            const float4 v = q.q4[k];
+            out[k] = make_float2(v.z, v.w);
+        }
+    }
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(1024)
+pairwise_loss_split_kernel(LossParams p, int nsplit, int part_major, float *ws, const float2 *prep)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // Query-major by default.  When all the parts fit the chip in one go (part_major), the parts of
@@ -1032,17 +1070,24 @@ pairwise_loss_split_kernel(LossParams p, int nsplit, int part_major, float *ws)
     const QueryLds q = carve_query_lds<KIND>(smem, L4, msplit);
     const size_t row = (size_t)b * L;
     stage_rows(q.sy, p.scores + row, p.rel, p.rel_dtype, row, L, nb, tid, T);
-    if (KIND == LTR_NDCG1 || KIND == LTR_NDCG2)
-        for (int m = tid; m < 2 * L4; m += T) q.rank_s[m] = 0;
     __syncthreads();
     if (KIND == LTR_NDCG1 || KIND == LTR_NDCG2) {
-        int owners = 64;
-        while (owners < L4 && owners < T) owners *= 2;
-        const int ms = T / owners;
-        const int mlen = (nb + ms - 1) / ms;
-        const int m0 = __builtin_amdgcn_readfirstlane(min(nb, (tid / owners) * mlen));
-        const int m1 = __builtin_amdgcn_readfirstlane(min(nb, m0 + mlen));
-        prepare_ndcg<KIND, 1>(q, nb, owners, tid % owners, m0, m1, ms > 1);
+        // the rankings were taken once per query by ndcg_prepare_kernel: prep[k] = (a_k, -) for
+        // LambdaNDCG1, (gain G_k / maxDCG, rank_k) for LambdaNDCG2
+        const float2 *pr = prep + row;
+        for (int k = tid; k < nb; k += T) {
+            const float2 v = pr[k];
+            if (KIND == LTR_NDCG1) {
+                q.sy[k].y = v.x;
+            } else {
+                const float2 sv = q.sy[k];
+                q.q4[k] = make_float4(sv.x, sv.y, v.x, v.y);
+            }
+        }
+        if (KIND == LTR_NDCG2)
+            for (int d = tid; d < nb; d += T)               // delta table, pairwise_lambda.py:206-211
+                q.delta[d] = fabsf(1.0f / log2f(2.0f + (float)d) - 1.0f / log2f(3.0f + (float)d));
+        __syncthreads();
     }
     float unused = 1.0f;
     const float raw = pairwise_core_sym<KIND>(q, nb, L4, p.sigma, unused, part, parts, true);
@@ -1623,9 +1668,11 @@ static int choose_loss_splits(int kind, int B, int L)
     // measured (hinge / logistic, us, plain kernel with the list-length order -> split launch):
     // 384 x 1000: 35/66 either way; 512 x 1000: 58/135 -> 43/90; 768 x 1000: 71/163 -> 69/149;
     // 1024 x 1000: 72/175 -> 78/180; 512 x 512: 18/37 -> 20/35; 768 x 300: 14/21 -> 17/27
-    // The NDCG kinds repeat their two rankings in every part (32 x 1000: 130 -> 61 us all the same,
-    // 128 x 600: 65 -> 50, 256 x 1000: 132 -> 118 / 146 -> 143); at 512 x 1000 that loses (161 -> 178)
+    // The NDCG kinds: rankings once per query by ndcg_prepare_kernel, then the same split (single
+    // kernel -> split, LambdaNDCG1/2: 32 x 1000: 130/144 -> 51/53 us; 128 x 600: 65/71 -> 46/48;
+    // C4 256 x 1000: 132/145 -> 82/90; 384 x 1000: 132/146 -> 114/123; 300 x 400: 41/43 -> 44/46)
     const bool ndcg = (kind == LTR_NDCG1 || kind == LTR_NDCG2);
+    if (ndcg && B > cus && L <= 512) return 1;
     if (2 * B > 3 * cus && !(!ndcg && B <= 2 * cus && L > 640)) return 1;
     int s = (LTR_SPLIT_MAX * cus) / (B > 0 ? B : 1);
     if (s > LTR_SPLIT_MAX) s = LTR_SPLIT_MAX;
@@ -1639,8 +1686,17 @@ static int launch_loss_split(const LossParams &p, int nsplit, float *ws, hipStre
     const size_t lds = loss_lds_bytes(KIND, (p.L + 63) & ~63, waves);
     LTR_ENSURE_LDS((pairwise_loss_split_kernel<KIND>), lds);
     const int part_major = (long long)p.B * nsplit <= device_cu_count() ? 1 : 0;
+    float2 *prep = nullptr;
+    if (KIND == LTR_NDCG1 || KIND == LTR_NDCG2) {
+        // (behind the raw sums and gradient slices; 8-byte aligned: an even number of floats precedes it)
+        prep = reinterpret_cast<float2 *>(ws + (((size_t)p.B * nsplit * ((size_t)p.L + 1) + 1) & ~(size_t)1));
+        constexpr int PK = (KIND == LTR_NDCG1 || KIND == LTR_NDCG2) ? KIND : LTR_NDCG1;
+        const size_t plds = loss_lds_bytes(PK, (p.L + 63) & ~63, 16);
+        LTR_ENSURE_LDS((ndcg_prepare_kernel<PK>), plds);
+        hipLaunchKernelGGL((ndcg_prepare_kernel<PK>), dim3((unsigned)p.B), dim3(1024), plds, stream, p, prep);
+    }
     hipLaunchKernelGGL((pairwise_loss_split_kernel<KIND>), dim3((unsigned)(p.B * nsplit)), dim3(64 * waves),
-                       lds, stream, p, nsplit, part_major, ws);
+                       lds, stream, p, nsplit, part_major, ws, (const float2 *)prep);
     hipLaunchKernelGGL((pairwise_loss_finish_kernel<KIND>), dim3((unsigned)p.B, (unsigned)((p.L + 255) / 256)),
                        dim3(256), 0, stream, p, nsplit, waves, (const float *)ws);
     return (int)hipGetLastError();
@@ -1765,7 +1821,10 @@ size_t ltr_pairwise_loss_workspace_bytes(int kind, int B, int L)
     if (B <= 0 || L <= 0) return 0;
     const int nsplit = choose_loss_splits(kind, B, L);
     if (nsplit <= 1) return 0;
-    return (size_t)B * nsplit * ((size_t)L + 1) * sizeof(float);
+    size_t floats = (size_t)B * nsplit * ((size_t)L + 1);
+    if (kind == LTR_NDCG1 || kind == LTR_NDCG2)
+        floats = ((floats + 1) & ~(size_t)1) + 2 * (size_t)B * L;      // + the prepared (gain, rank) pairs
+    return floats * sizeof(float);
 }
 
 int ltr_pairwise_loss_ws_f32(int kind, float sigma, const float *scores, const void *rel,
