@@ -119,12 +119,17 @@ class FusedLinearLoss(torch.nn.Module):
                                          self.sigma, bool(return_scores))
 
     def _prefer_pieces(self, B, L):
-        # measured on MI355X (scripts/bench_scorer.py): 32 x 1000 x 220 pieces 71 us vs fused 95;
-        # 256 x 1000 x 220 pieces 120 us vs fused 104
+        # measured on MI355X, fused kernel -> pieces, us (B x L x F; hinge / logistic / LambdaNDCG2):
+        #   32 x 1000 x 220:  78/136/173 -> 46/52/77      128 x 1000 x 220: 84/145/181 -> 55/66/93
+        #   256 x 1000 x 220: 86/145/183 -> 87/113/147    384 x 1000 x 220: 90/149/186 -> 114/149/204
+        #   128 x 600 x 136:  41/64/90 -> 39/47/72        256 x 600 x 136:  44/66/93 -> 48/60/89
         if B <= 0 or _C.lib().ltr_pairwise_loss_workspace_bytes(self.kind, B, L) == 0:
             return False
         cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-        return 2 * B <= cus
+        if 2 * B <= cus:
+            return True
+        heavy_pairs = self.kind not in (_C.HINGE, _C.DCG_HINGE)
+        return heavy_pairs and B <= cus and L > 768
 
 
 def linear_loss_step(xs, weight, bias, relevance, n, loss="hinge", grad_out=None,
