@@ -200,3 +200,47 @@ def test_split_query_launch_through_the_module_and_forward_only():
     assert torch.allclose(out.detach(), ref_l, rtol=2e-5, atol=1e-5)
     scale = ref_g.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
     assert bool(((s.grad - ref_g).abs() <= 2e-5 * scale + 1e-6).all())
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_shapes_in_the_scheduled_and_split_ranges(seed):
+    """Random (B, L, kind, list-length pattern) in the ranges where block ids are mapped to queries
+    by the in-kernel list-length order or a query is split over workgroups; both entry points
+    against the oracle (NaN prefill: every loss / gradient row written exactly by its query)."""
+    from pytorchltr_amd import _C
+    rng = np.random.default_rng(1000 + seed)
+    dev = torch.device("cuda")
+    B = int(rng.integers(270, 1100)) if seed % 3 else int(rng.integers(20, 400))
+    L = int(rng.integers(65, 330)) if seed % 3 else int(rng.integers(257, 900))
+    kind = KINDS[int(rng.integers(0, len(KINDS)))]
+    scores, y, n = synth(B, L, 5000 + seed)
+    pattern = int(rng.integers(0, 4))
+    if pattern == 1:
+        n = torch.full_like(n, L)
+    elif pattern == 2:
+        n = torch.where(torch.rand(B, generator=torch.Generator().manual_seed(seed)) < 0.7,
+                        torch.full_like(n, L), n)
+    elif pattern == 3:
+        n = torch.clamp(n // 8, min=0)
+    lib = _C.lib()
+    kid = getattr(_C, kind.upper())
+    sd, yd, nd = scores.to(dev), y.to(dev), n.to(dev)
+    want_l, want_g = O.pairwise_loss(kind, scores.numpy(), y.numpy(), n.numpy())
+    for entry in ("plain", "workspace"):
+        loss = torch.full((B,), float("nan"), device=dev)
+        ds = torch.full((B, L), float("nan"), device=dev)
+        if entry == "plain":
+            rc = lib.ltr_pairwise_loss_f32(kid, 1.0, sd.data_ptr(), yd.data_ptr(), _C.label_dtype(yd),
+                                           nd.data_ptr(), B, L, loss.data_ptr(), ds.data_ptr(), _C.stream_of(sd))
+        else:
+            wsb = lib.ltr_pairwise_loss_workspace_bytes(kid, B, L)
+            ws = torch.empty(max(wsb, 4) // 4, device=dev)
+            rc = lib.ltr_pairwise_loss_ws_f32(kid, 1.0, sd.data_ptr(), yd.data_ptr(), _C.label_dtype(yd),
+                                              nd.data_ptr(), B, L, loss.data_ptr(), ds.data_ptr(),
+                                              ws.data_ptr(), wsb, _C.stream_of(sd))
+        _C.check(rc)
+        torch.cuda.synchronize()
+        what = "%s B=%d L=%d %s pattern %d" % (entry, B, L, kind, pattern)
+        assert not torch.isnan(loss).any() and not torch.isnan(ds).any(), what
+        _check_loss(loss.cpu().numpy(), want_l, L, what)
+        _check_grad(ds.cpu().numpy(), want_g, what)
