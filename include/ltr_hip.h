@@ -89,9 +89,9 @@ int ltr_pairwise_loss_f32_cfg(int kind, float sigma, const float *scores, const 
                               float *dscores, int owners, int dpt, int msplit, void *stream);
 
 /* Same result as ltr_pairwise_loss_f32 for batches where one workgroup per query cannot balance
- * the machine (lists longer than 256 on a batch of fewer than ~8 queries per CU, e.g. 256 x 1000):
- * up to 8 workgroups share a query's pair work, a finish kernel adds their parts in a fixed order
- * (deterministic).  workspace: ltr_pairwise_loss_workspace_bytes(kind, B, L) bytes (0 = the plain path
+ * the machine (lists longer than 256 on a batch of at most ~2 queries per CU, e.g. 256 x 1000):
+ * up to 8 workgroups share a query's pair work (for the NDCG kinds after one ranking pre-pass per
+ * query), a finish kernel adds their parts in a fixed order (deterministic).  workspace: ltr_pairwise_loss_workspace_bytes(kind, B, L) bytes (0 = the plain path
  * is taken and workspace may be NULL).  Replaces the same reference symbols as
  * ltr_pairwise_loss_f32. */
 size_t ltr_pairwise_loss_workspace_bytes(int kind, int B, int L);
