@@ -193,6 +193,12 @@ int ltr_collate_pad_f32(const float *xs, const int64_t *ys, const int64_t *offse
  * `workspace` needs ltr_linear_workspace_bytes(B,L,F) bytes (per-query partials).
  */
 size_t ltr_linear_workspace_bytes(int B, int L, int F);
+/* Which kernel ltr_linear_partials_f32 / ltr_linear_pairwise_f32 take for this shape when no score
+ * output is requested and X is 16-byte aligned: the register tile (features cross HBM once, one
+ * workgroup per query), the cluster kernel (features once, a query spread over several workgroups:
+ * long lists on small batches, rank-free kinds) or the general kernel (features twice). */
+enum { LTR_PLAN_NONE = 0, LTR_PLAN_REGISTER_TILE = 1, LTR_PLAN_CLUSTER = 2, LTR_PLAN_GENERAL = 3 };
+int ltr_linear_fused_plan(int kind, int B, int L, int F);
 int ltr_linear_pairwise_f32(int kind, float sigma, const float *X, const float *W,
                             const float *bias, const void *rel, int rel_dtype,
                             const int64_t *n, const float *grad_out, int B, int L, int F,

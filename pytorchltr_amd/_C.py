@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libltr_hip.so")
 HINGE, DCG_HINGE, LOGISTIC, ARP1, ARP2, NDCG1, NDCG2 = range(7)
 # enum ltr_label_dtype
 LABEL_I64, LABEL_F32, LABEL_I32 = 0, 1, 2
+# ltr_linear_fused_plan (include/ltr_hip.h)
+PLAN_NONE, PLAN_REGISTER_TILE, PLAN_CLUSTER, PLAN_GENERAL = 0, 1, 2, 3
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 
@@ -39,6 +41,7 @@ SIGNATURES = {
     "ltr_pbm_clicks": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
     "ltr_collate_pad_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ltr_linear_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ltr_linear_fused_plan": (_i, [_i, _i, _i, _i]),
     "ltr_linear_pairwise_f32": (_i, [_i, _f, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i,
                                      _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ltr_linear_partials_f32": (_i, [_i, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i,

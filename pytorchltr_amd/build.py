@@ -12,9 +12,9 @@ _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libltr_hip.so")
 SOURCES = [os.path.join(CSRC, "ltr_kernels.hip")]
-DEPENDS = SOURCES + [os.path.join(CSRC, "ltr_linear.inc"), os.path.join(CSRC, "ltr_f64.inc"),
-                     os.path.join(CSRC, "ltr_mlp.inc"), os.path.join(CSRC, "ltr_scorer.inc"),
-                     os.path.join(_ROOT, "include", "ltr_hip.h")]
+# every .inc the translation unit includes, and the public header
+DEPENDS = SOURCES + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".inc")) + \
+    [os.path.join(_ROOT, "include", "ltr_hip.h")]
 ARCH = "gfx950"
 IO_LIB_PATH = os.path.join(CSRC, "libltr_io.so")
 IO_SOURCES = [os.path.join(CSRC, "svmrank_parser.cpp")]

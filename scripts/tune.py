@@ -41,7 +41,6 @@ def main():
     W = torch.randn(F, device=dev) * 0.1
     bias = torch.zeros(1, device=dev)
     loss = torch.empty(B, device=dev)
-    part = torch.empty(B * (F + 1) + 1024, device=dev)
     ds = torch.empty(B, L, device=dev)
     dW = torch.empty(F, device=dev)
     db = torch.empty(1, device=dev)
@@ -52,6 +51,7 @@ def main():
     so_ptr = trbuf.data_ptr() if args.trace else None
     for path in args.libs:
         lib = load(path)
+        part = torch.empty(lib.ltr_linear_workspace_bytes(B, L, F) // 4 + 64, device=dev)
 
         def cs():
             return torch.cuda.current_stream().cuda_stream

@@ -235,3 +235,38 @@ def test_list_length_scheduling_in_the_general_fused_kernel(kind):
     _check(kind, 300, 300, 64, 9)
     _check(kind, 1100, 128, 6, 10)
     _check(kind, 310, 260, 12, 11, full=True)
+
+
+@pytest.mark.parametrize("kind", ["hinge", "dcg_hinge", "logistic", "arp1", "arp2"])
+@pytest.mark.parametrize("shape", [(5, 700, 136), (33, 1000, 220), (16, 512, 700), (64, 300, 136)])
+def test_cluster_kernel_long_lists_on_small_batches(kind, shape):
+    """Long lists on a small batch: a query is spread over a cluster of workgroups that keep its
+    rows in registers and exchange scores / gradient slices through device memory (features read
+    once).  Same step as the oracle's, including queries that are empty, have one document, end
+    exactly at / just past a workgroup's row range, or are full; and bit-identical from run to run."""
+    from pytorchltr_amd import _C
+    from pytorchltr_amd.fused import linear_loss_step
+    B, L, F = shape
+    lib = _C.lib()
+    kid = getattr(_C, kind.upper())
+    plan = lib.ltr_linear_fused_plan(kid, B, L, F)
+    if shape == (64, 300, 136):
+        assert plan == _C.PLAN_GENERAL          # one workgroup's registers hold 360 rows: no cluster
+    else:
+        assert plan == _C.PLAN_CLUSTER
+    dev = _dev()
+    s, y, n, X, W, b = synth(B, L, 31, F=F)
+    rpw = 12 * (1024 // (F // 4))
+    n[:5] = torch.tensor([0, 1, min(L, rpw), min(L, rpw + 1), L])[:min(5, B)]
+    gout = torch.linspace(0.2, 1.7, B)
+    Xd, Wd, bd, yd, nd = X.to(dev), W.to(dev), b.to(dev), y.to(dev), n.to(dev)
+    loss, dW, db = linear_loss_step(Xd, Wd, bd, yd, nd, loss=kind, grad_out=gout.to(dev))
+    want_l, _, want_dW, want_db = O.linear_pairwise(kind, X.numpy(), W.numpy(), float(b[0]), y.numpy(),
+                                                    n.numpy(), gout.numpy().astype(np.float64), sigma=1.0)
+    rtol = 5e-4 if L > 256 else 2e-5
+    assert np.allclose(loss.cpu().numpy(), want_l, rtol=rtol, atol=1e-5), kind
+    tol = 2e-4 * max(1.0, float(np.max(np.abs(want_dW))))
+    assert np.max(np.abs(dW.cpu().numpy() - want_dW)) < tol, kind
+    assert abs(float(db.cpu()[0]) - want_db) < tol, kind
+    loss2, dW2, db2 = linear_loss_step(Xd, Wd, bd, yd, nd, loss=kind, grad_out=gout.to(dev))
+    assert torch.equal(loss, loss2) and torch.equal(dW, dW2) and torch.equal(db, db2)
