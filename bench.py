@@ -57,14 +57,12 @@ def synth(B, L, F, seed, device):
     return scores.to(device), relevance.to(device), n.to(device), X.to(device)
 
 
-def fused_kernel_name(L, F):
-    """Which kernel ltr_linear_partials_f32 dispatches to (mirrors choose_regtile_shape)."""
-    if F % 4 == 0 and L <= 512:
-        C = F // 4
-        R = 512 // C if C <= 512 else 0
-        if R > 0 and (L + R - 1) // R <= 9:
-            return "linear_regtile_kernel"
-    return "linear_pairwise_kernel"
+def fused_kernel_name(kind_id, B, L, F):
+    """Which kernel ltr_linear_partials_f32 dispatches to for this shape (asks the library)."""
+    from pytorchltr_amd import _C
+    plan = _C.lib().ltr_linear_fused_plan(kind_id, B, L, F)
+    return {_C.PLAN_REGISTER_TILE: "linear_regtile_kernel", _C.PLAN_CLUSTER: "linear_cluster_kernel",
+            _C.PLAN_GENERAL: "linear_pairwise_kernel"}.get(plan, "?")
 
 
 def time_events(fn, iters):
@@ -391,7 +389,7 @@ def main():
                 traffic = json.load(fh).get("hbm_bytes_per_launch")
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "kernel": "%s<%s> (via ltr_linear_partials_f32)" % (fused_kernel_name(L, F), kind),
+                    "kernel": "%s<%s> (via ltr_linear_partials_f32)" % (fused_kernel_name(kind_id, B, L, F), kind),
                     "kernel_us_avg": k_avg,
                     "timing": "HIP events around %s back-to-back launches" % ("hipGraph-replayed" if k_graphed else "eager"),
                     "kernel_us_single_launch_event_pair": {"avg": k_evt_avg, "median": k_evt_med, "min": k_evt_min},

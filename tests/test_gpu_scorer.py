@@ -84,28 +84,29 @@ def test_reference_user_code_against_oracle(kind):
 
 
 def test_fused_linear_loss_takes_the_pieces_for_a_few_long_lists():
-    """FusedLinearLoss on a small batch of long lists runs as scorer + split-query loss + weight
-    gradient kernels; same loss and gradients as the one-kernel fused path (forced via the C ABI
+    """FusedLinearLoss on a small batch of long lists with an NDCG loss (the cluster kernel takes the
+    rank-free kinds) runs as scorer + split-query loss + weight gradient kernels; same loss and gradients as the one-kernel fused path (forced via the C ABI
     step function) and as the oracle."""
     from oracle import ltr_oracle as O
     from pytorchltr_amd.fused import FusedLinearLoss, linear_loss_step
     dev = torch.device("cuda")
     B, L, F = 20, 700, 64
     s, y, n, X, W, b = synth(B, L, 9, F=F)
-    m = FusedLinearLoss(F, "logistic").to(dev)
+    m = FusedLinearLoss(F, "ndcg2").to(dev)
     assert m._prefer_pieces(B, L)
+    assert not FusedLinearLoss(F, "logistic").to(dev)._prefer_pieces(B, L)      # cluster kernel instead
     with torch.no_grad():
         m.weight.copy_(W.reshape(1, F))
         m.bias.copy_(b)
     loss, scores = m(X.to(dev), y.to(dev), n.to(dev), return_scores=True)
     loss.mean().backward()
-    ref_l, ref_dW, ref_db = linear_loss_step(X.to(dev), m.weight, m.bias, y.to(dev), n.to(dev), loss="logistic")
-    assert torch.allclose(loss.detach(), ref_l, rtol=2e-5, atol=1e-5)
+    ref_l, ref_dW, ref_db = linear_loss_step(X.to(dev), m.weight, m.bias, y.to(dev), n.to(dev), loss="ndcg2")
+    assert torch.allclose(loss.detach(), ref_l, rtol=5e-4, atol=1e-5)
     scale = float(ref_dW.abs().max())
     assert torch.allclose(m.weight.grad.reshape(-1), ref_dW, rtol=1e-4, atol=2e-5 * max(1.0, scale))
     assert torch.allclose(m.bias.grad, ref_db, atol=1e-4 * max(1.0, scale))
-    want_l, want_s, _, _ = O.linear_pairwise("logistic", X[:3].numpy(), W.numpy(), float(b), y[:3].numpy(),
+    want_l, want_s, _, _ = O.linear_pairwise("ndcg2", X[:3].numpy(), W.numpy(), float(b), y[:3].numpy(),
                                              n[:3].numpy(), np.full(3, 1.0 / 3))
-    assert np.allclose(loss.detach().cpu().numpy()[:3], want_l, rtol=2e-5, atol=1e-5)
+    assert np.allclose(loss.detach().cpu().numpy()[:3], want_l, rtol=5e-4, atol=1e-5)
     valid = np.arange(L)[None, :] < n[:3].numpy()[:, None]
     assert np.allclose(scores.cpu().numpy()[:3][valid], want_s[valid], rtol=1e-5, atol=1e-5)
