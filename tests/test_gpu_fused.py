@@ -237,7 +237,7 @@ def test_list_length_scheduling_in_the_general_fused_kernel(kind):
     _check(kind, 310, 260, 12, 11, full=True)
 
 
-@pytest.mark.parametrize("kind", ["hinge", "dcg_hinge", "logistic", "arp1", "arp2"])
+@pytest.mark.parametrize("kind", ["hinge", "dcg_hinge", "logistic", "arp1", "arp2", "ndcg1", "ndcg2"])
 @pytest.mark.parametrize("shape", [(5, 700, 136), (33, 1000, 220), (16, 512, 700), (64, 300, 24)])
 def test_cluster_kernel_long_lists_on_small_batches(kind, shape):
     """Long lists on a small batch: a query is spread over a cluster of workgroups that keep its
