@@ -270,3 +270,30 @@ def test_cluster_kernel_long_lists_on_small_batches(kind, shape):
     assert abs(float(db.cpu()[0]) - want_db) < tol, kind
     loss2, dW2, db2 = linear_loss_step(Xd, Wd, bd, yd, nd, loss=kind, grad_out=gout.to(dev))
     assert torch.equal(loss, loss2) and torch.equal(dW, dW2) and torch.equal(db, db2)
+
+
+def test_out_of_range_list_lengths_under_the_scheduling():
+    """n[b] < 0 or > list_len is clamped exactly as on the unscheduled paths (the scheduling pass
+    orders by the clamped value and hands it to the kernel)."""
+    from pytorchltr_amd.fused import linear_loss_step
+    from pytorchltr_amd._autograd import pairwise_loss_and_grad
+    from pytorchltr_amd import _C
+    dev = _dev()
+    B, L, F = 600, 128, 136
+    s, y, n, X, W, b = synth(B, L, 99, F=F)
+    wild = n.clone()
+    wild[::7] = -3
+    wild[3::11] = L + 50
+    tame = wild.clamp(0, L)
+    Xd, Wd, bd, yd = X.to(dev), W.to(dev), b.to(dev), y.to(dev)
+    a = linear_loss_step(Xd, Wd, bd, yd, wild.to(dev), loss="logistic")
+    c = linear_loss_step(Xd, Wd, bd, yd, tame.to(dev), loss="logistic")
+    assert all(torch.equal(u, v) for u, v in zip(a, c))
+    B2 = 1100
+    s2, y2, n2 = synth(B2, L, 98)[:3]
+    wild2 = n2.clone()
+    wild2[::5] = -1
+    wild2[2::9] = 10 * L
+    l1, g1 = pairwise_loss_and_grad(s2.to(dev), y2.to(dev), wild2.to(dev), _C.NDCG2)
+    l2, g2 = pairwise_loss_and_grad(s2.to(dev), y2.to(dev), wild2.clamp(0, L).to(dev), _C.NDCG2)
+    assert torch.equal(l1, l2) and torch.equal(g1, g2)
