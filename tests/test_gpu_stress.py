@@ -244,3 +244,38 @@ def test_random_shapes_in_the_scheduled_and_split_ranges(seed):
         assert not torch.isnan(loss).any() and not torch.isnan(ds).any(), what
         _check_loss(loss.cpu().numpy(), want_l, L, what)
         _check_grad(ds.cpu().numpy(), want_g, what)
+
+
+def test_cluster_kernel_soak():
+    """Many launches of the cluster kernel over random eligible shapes: its spin-waits must always
+    complete (a stall is bounded and shows up as a NaN loss, never as a hung GPU)."""
+    import random
+    from pytorchltr_amd import _C
+    lib = _C.lib()
+    dev = torch.device("cuda")
+    rnd = random.Random(7)
+    launches = 0
+    for it in range(120):
+        B = rnd.choice([3, 17, 64, 100, 192, 256, 384])
+        L = rnd.choice([300, 400, 512, 700, 1000, 1024])
+        F = rnd.choice([64, 136, 220, 700])
+        kid = rnd.randrange(7)
+        if lib.ltr_linear_fused_plan(kid, B, L, F) != _C.PLAN_CLUSTER or B * L * F > 60e6:
+            continue
+        g = torch.Generator().manual_seed(it)
+        X = torch.randn(B, L, F, generator=g).to(dev)
+        y = torch.randint(0, 5, (B, L), generator=g).to(dev)
+        n = torch.randint(0, L + 1, (B,), generator=g).to(dev)
+        W = (torch.randn(F, generator=g) * 0.1).to(dev)
+        bias = torch.zeros(1, device=dev)
+        loss = torch.full((B,), float("nan"), device=dev)
+        part = torch.empty(lib.ltr_linear_workspace_bytes(B, L, F) // 4, device=dev)
+        for _ in range(4):
+            _C.check(lib.ltr_linear_partials_f32(kid, 1.0, X.data_ptr(), W.data_ptr(), bias.data_ptr(), y.data_ptr(),
+                                                 _C.label_dtype(y), n.data_ptr(), B, L, F, loss.data_ptr(), None,
+                                                 part.data_ptr(), _C.stream_of(X)))
+            launches += 1
+        torch.cuda.synchronize()
+        assert not torch.isnan(loss).any(), (B, L, F, kid)
+        assert not torch.isnan(part[:B * (F + 1)]).any(), (B, L, F, kid)
+    assert launches >= 100
