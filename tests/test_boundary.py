@@ -170,3 +170,20 @@ def test_prepare_shapes_and_dtypes_host_logic(monkeypatch):
     assert _C.label_dtype(torch.zeros(1, dtype=torch.int64)) == _C.LABEL_I64
     assert _C.label_dtype(torch.zeros(1, dtype=torch.int32)) == _C.LABEL_I32
     assert _C.label_dtype(torch.zeros(1)) == _C.LABEL_F32
+
+
+def test_fused_plan_for_the_baseline_shapes():
+    """ltr_linear_fused_plan is host logic (no launch): which kernel the fused Linear scorer + loss
+    step takes for the BASELINE.json shapes (256 CUs assumed when no device is present)."""
+    from pytorchltr_amd import _C
+    lib = _C.lib()
+    assert lib.ltr_linear_fused_plan(_C.HINGE, 1024, 128, 136) == _C.PLAN_REGISTER_TILE      # C2
+    assert lib.ltr_linear_fused_plan(_C.NDCG2, 1024, 128, 136) == _C.PLAN_REGISTER_TILE      # C3
+    assert lib.ltr_linear_fused_plan(_C.DCG_HINGE, 256, 1000, 220) == _C.PLAN_CLUSTER        # C4
+    assert lib.ltr_linear_fused_plan(_C.HINGE, 512, 512, 700) == _C.PLAN_GENERAL             # C5
+    assert lib.ltr_linear_fused_plan(_C.NDCG2, 256, 1000, 220) == _C.PLAN_GENERAL            # rankings: small batches only
+    assert lib.ltr_linear_fused_plan(_C.NDCG2, 32, 1000, 220) == _C.PLAN_CLUSTER
+    assert lib.ltr_linear_fused_plan(_C.HINGE, 8, 5000, 136) == _C.PLAN_NONE                 # list_len > 4096
+    assert lib.ltr_linear_fused_plan(99, 8, 100, 136) == _C.PLAN_NONE
+    # the cluster kernel's scratch rides behind the (F+1, B) partials
+    assert lib.ltr_linear_workspace_bytes(256, 1000, 220) > lib.ltr_linear_workspace_bytes(256, 128, 220)
