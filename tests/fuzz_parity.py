@@ -2,7 +2,7 @@
 """Randomised parity fuzz on the GPU: loss kernel (plain and workspace entry points) and the fused
 Linear scorer + loss step against the fp64 C oracle, over random (kind, B, L, F, list-length
 pattern, sigma).  Test infrastructure (uses oracle/); not part of the test tiers because it runs
-for minutes:   python scripts/fuzz_parity.py SEED SECONDS
+for minutes (not collected by pytest):   python tests/fuzz_parity.py SEED SECONDS
 
 Known benign report: "hinge ... grad ok False" on large shapes -- a pair whose margin is within one
 fp32 ulp of 0 flips activity against the fp64 oracle."""
