@@ -2,7 +2,7 @@
 """Host-side timing of the SVMrank parser (libltr_io) next to the reference's own C parser
 (oracle/_ref/libsvmrank_ref.so, when present) on a synthetic MSLR-shaped file.
 
-    python scripts/bench_parser.py [--rows 120000 --features 136]"""
+    python tests/bench_parser.py [--rows 120000 --features 136]"""
 import argparse
 import json
 import os
