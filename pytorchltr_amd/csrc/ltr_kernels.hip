@@ -1132,11 +1132,13 @@ pairwise_loss_finish_kernel(LossParams p, int nsplit, int waves, const float *ws
         if (k < L) {
             float g = 0.f;
             if (k < nb) {
-                float v[LTR_SPLIT_MAX];
+                for (int s0 = 0; s0 < parts; s0 += 8) {             // eight independent loads at a time
+                    float v[8];
 #pragma unroll
-                for (int s = 0; s < LTR_SPLIT_MAX; ++s) v[s] = (s < parts) ? wg[(size_t)s * L + k] : 0.f;
+                    for (int s = 0; s < 8; ++s) v[s] = (s0 + s < parts) ? wg[(size_t)(s0 + s) * L + k] : 0.f;
 #pragma unroll
-                for (int s = 0; s < LTR_SPLIT_MAX; ++s) g += v[s];   // fixed order; the extra terms are +0
+                    for (int s = 0; s < 8; ++s) g += v[s];          // fixed order; the extra terms are +0
+                }
                 g *= gscale;
             }
             p.dscores[(size_t)b * L + k] = g;
@@ -1675,8 +1677,11 @@ static int choose_loss_splits(int kind, int B, int L)
     const bool ndcg = (kind == LTR_NDCG1 || kind == LTR_NDCG2);
     if (ndcg && B > cus && L <= 512) return 1;
     if (2 * B > 3 * cus && !(!ndcg && B <= 2 * cus && L > 640)) return 1;
+    // up to 8 parts per query; 16 on the smallest batches (64 x 1000: hinge 22.4 -> 16.5 us, logistic
+    // 28.6 -> 20.7, LambdaNDCG2 55 -> 45; at 128 x 600 and above 8 is better)
+    const int cap = (4 * B <= cus) ? 2 * LTR_SPLIT_MAX : LTR_SPLIT_MAX;
     int s = (LTR_SPLIT_MAX * cus) / (B > 0 ? B : 1);
-    if (s > LTR_SPLIT_MAX) s = LTR_SPLIT_MAX;
+    if (s > cap) s = cap;
     return s < 2 ? 1 : s;
 }
 
