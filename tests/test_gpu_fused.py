@@ -256,7 +256,13 @@ def test_cluster_kernel_long_lists_on_small_batches(kind, shape):
         assert plan == _C.PLAN_CLUSTER
     dev = _dev()
     s, y, n, X, W, b = synth(B, L, 31, F=F)
-    rpw = ((12 if (L >= 768 and 4 * B > 256) else 8) * (512 // (F // 4))) if F // 4 <= 128 else (19 * (1024 // (F // 4)))
+    if F // 4 <= 128:
+        R = 512 // (F // 4)
+        rpw = 8 * R
+        if -(-L // rpw) > 16 or (-(-L // rpw) > 6 and 4 * B > 256):
+            rpw = 12 * R
+    else:
+        rpw = 19 * (1024 // (F // 4))
     n[:5] = torch.tensor([0, 1, min(L, rpw), min(L, rpw + 1), L])[:min(5, B)]
     gout = torch.linspace(0.2, 1.7, B)
     Xd, Wd, bd, yd, nd = X.to(dev), W.to(dev), b.to(dev), y.to(dev), n.to(dev)
