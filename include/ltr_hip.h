@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LTR_VERSION 100 /* 0.1.0 */
+#define LTR_VERSION 110 /* 0.1.1 */
 
 /* Loss kinds: one per class exported by pytorchltr/loss/__init__.py:1-7. */
 enum ltr_loss_kind {
@@ -61,11 +61,28 @@ enum ltr_label_dtype {
 #define LTR_ERR_LIST_TOO_LONG (-4) /* L > ltr_max_list_len()                       */
 #define LTR_ERR_WORKSPACE (-5)   /* workspace NULL or smaller than ltr_*_workspace_bytes */
 #define LTR_ERR_CONFIG (-6)      /* invalid explicit launch configuration          */
+#define LTR_ERR_TIMEOUT (-7)     /* a multi-workgroup kernel gave up waiting (see ltr_device_status) */
 
 int ltr_version(void);
 const char *ltr_error_string(int code);
-/* Largest list_len one workgroup's LDS holds (all kinds). */
+/* Largest list_len one workgroup's LDS holds (all kinds, fp32 entry points). */
 int ltr_max_list_len(void);
+/* The same for the fp64 entry point (ltr_pairwise_loss_f64 keeps four double arrays in LDS). */
+int ltr_max_list_len_f64(void);
+
+/*
+ * Sticky device status.  The kernels whose workgroups wait for each other inside one launch (the
+ * cluster kernel behind ltr_linear_partials_f32 / ltr_linear_pairwise_f32 for long lists on small
+ * batches) bound every wait; a wait that gives up poisons the query's outputs with NaN AND stores
+ * LTR_ERR_TIMEOUT in a pinned, device-mapped status word of the process.  The ltr_linear_* entry
+ * points return that code on the next call (a host read, no synchronisation); this function returns
+ * the current word (0 = OK) and, with clear != 0, resets it.  Synchronise the stream first when the
+ * answer must cover work that is still in flight.  The reference has no counterpart: its ops cannot
+ * fail at run time.
+ */
+int ltr_device_status(int clear);
+/* Tests only: != 0 makes every in-launch wait of the cluster kernel give up at once. */
+void ltr_debug_force_timeout(int on);
 
 /*
  * Seven pairwise losses, forward + analytic gradient in ONE pass.
@@ -106,6 +123,11 @@ int ltr_pairwise_loss_ws_f32(int kind, float sigma, const float *scores, const v
  */
 int ltr_scale_rows_f32(const float *dscores, const float *grad_out, int B, int L, float *out,
                        void *stream);
+/* The same with ONE upstream gradient for every query, read from device memory: out = grad[0] *
+ * dscores -- what `loss.mean().backward()` / `loss.sum().backward()` hand to the loss (autograd
+ * passes an expanded, stride-0 tensor; this skips materialising it). */
+int ltr_scale_rows_uniform_f32(const float *dscores, const float *grad_scalar, int B, int L,
+                               float *out, void *stream);
 
 /*
  * Double-precision instantiation of the two entry points above.  The reference computes in the
@@ -135,6 +157,32 @@ int ltr_dcg_f32(const float *scores, const void *rel, int rel_dtype, const int64
 /* arp, evaluation/arp.py:7-42.  out is (B). */
 int ltr_arp_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n, int B,
                 int L, float *out, void *stream);
+
+/*
+ * The three ranking entry points above with the reference's RANDOM tie-break
+ * (tiebreak_argsort, utils/tensor_operations.py:29-45: one permutation p = randperm(L) shared by
+ * all rows decides the order of equal scores).  `tie` (L) int32 is a permutation of 0..L-1 drawn by
+ * the caller: among documents with equal (masked) score the one with the SMALLER tie[j] ranks first.
+ * tie == NULL is the deterministic index order of the plain entry points.  Rows without ties give
+ * the same result for every `tie`.
+ */
+int ltr_rank_by_score_tie_f32(const float *scores, const int64_t *n, const int32_t *tie, int B, int L,
+                              int64_t *ranking, void *stream);
+int ltr_dcg_tie_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n,
+                    const int32_t *tie, int B, int L, int k, int use_exp, int normalize, float *out,
+                    void *stream);
+int ltr_arp_tie_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n,
+                    const int32_t *tie, int B, int L, float *out, void *stream);
+
+/*
+ * Listwise softmax cross-entropy (ListNet top-one; named by the project brief, ABSENT from the
+ * reference: pytorchltr/loss/__init__.py:1-7 exports no such class -- parity unpinned, the
+ * specification is this header):
+ *   P_y = softmax(y[b, :n]),  P_s = softmax(s[b, :n]),  loss[b] = -sum_j P_y(j) * ln P_s(j)
+ *   dscores[b, j] = P_s(j) - P_y(j) for j < n[b], 0 after;  n[b] == 0 gives loss 0.
+ */
+int ltr_listwise_softmax_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n,
+                             int B, int L, float *loss, float *dscores, void *stream);
 
 /* mask_padded_values, utils/tensor_operations.py:6-26: out[b,j] = j >= n[b] ? mask_value
  * : xs[b,j].  `out` may alias `xs` (mutate=True). */
@@ -221,6 +269,11 @@ int ltr_linear_reduce_f32(const float *partials, const float *grad_out, int B, i
  * logs / all-reduces) in the same launch.  loss_sum may be NULL. */
 int ltr_linear_reduce_loss_f32(const float *partials, const float *grad_out, const float *loss,
                                int B, int F, float *dW, float *db, float *loss_sum, void *stream);
+/* The same with accumulate != 0: dW, db and loss_sum are ADDED to (gradient accumulation over
+ * micro-batches before one all-reduce / optimizer step, as autograd's AccumulateGrad does). */
+int ltr_linear_reduce_accum_f32(const float *partials, const float *grad_out, const float *loss,
+                                int B, int F, float *dW, float *db, float *loss_sum, int accumulate,
+                                void *stream);
 
 /* --- fused ReLU-MLP scorer + loss + backward --------------------
  * Replaces the user-side composition `loss_fn(model(xs), ys, n)` + `.backward()` with `model` the

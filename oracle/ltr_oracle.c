@@ -87,6 +87,20 @@ int oracle_batch_pairs(const double *x, int B, int L, double *out)
 /* One row of rank_by_score, utils/tensor_operations.py:48-64 (which is
  * mask_padded_values(-inf) :6-26 followed by a descending argsort :29-45).
  * ranking[r] = index of the document at rank r.  Tie rule: see file header. */
+/* Optional tie priorities (oracle_set_tie): the reference's tiebreak_argsort,
+ * utils/tensor_operations.py:29-45, lets ONE random permutation shared by all rows decide the
+ * order of equal scores; with priorities set, of two REAL documents with equal score the one
+ * with the smaller priority ranks first (NULL: index order, the deterministic default).  The
+ * padded tail stays in index order either way. */
+static const int32_t *g_tie = NULL;
+void oracle_set_tie(const int32_t *tie) { g_tie = tie; }
+
+static int tie_before(int m, int j, int nb)
+{
+    if (g_tie && m < nb && j < nb) return g_tie[m] < g_tie[j];
+    return m < j;
+}
+
 static void rank_row(const double *s, int nb, int L, int64_t *ranking)
 {
     for (int j = 0; j < L; ++j) {
@@ -94,7 +108,7 @@ static void rank_row(const double *s, int nb, int L, int64_t *ranking)
         int r = 0;
         for (int m = 0; m < L; ++m) {
             double km = (m < nb) ? s[m] : -INFINITY;
-            if (km > kj || (km == kj && m < j)) ++r;
+            if (km > kj || (km == kj && tie_before(m, j, nb))) ++r;
         }
         ranking[r] = j;
     }
@@ -446,4 +460,28 @@ int oracle_mlp_pairwise(int kind, double sigma, const double *X, const double *W
     }
     free(scores); free(ds); free(h1); free(h2); free(d1); free(d2);
     return rc;
+}
+
+/* Listwise softmax cross-entropy (ListNet top-one).  NOT in the reference
+ * (pytorchltr/loss/__init__.py:1-7 exports seven pairwise classes only): PARITY UNPINNED -- this is
+ * the builder's own specification (include/ltr_hip.h: ltr_listwise_softmax_f32), restated here in
+ * fp64 and checked by finite differences in tests/test_listwise.py.
+ *   loss[b] = -sum_{j<n} softmax(y[b,:n])_j * ln softmax(s[b,:n])_j;  d/ds_j = P_s(j) - P_y(j). */
+int oracle_listwise_softmax(const double *scores, const double *rel, const int64_t *n, int B, int L,
+                            double *loss, double *dscores)
+{
+    for (int b = 0; b < B; ++b) {
+        const double *s = scores + (size_t)b * L, *y = rel + (size_t)b * L;
+        int nb = clamp_n(n[b], L);
+        double ms = -INFINITY, my = -INFINITY, zs = 0.0, zy = 0.0, acc = 0.0;
+        for (int j = 0; j < nb; ++j) { if (s[j] > ms) ms = s[j]; if (y[j] > my) my = y[j]; }
+        for (int j = 0; j < nb; ++j) { zs += exp(s[j] - ms); zy += exp(y[j] - my); }
+        for (int j = 0; j < nb; ++j)
+            acc -= exp(y[j] - my) / zy * ((s[j] - ms) - log(zs));
+        loss[b] = nb > 0 ? acc : 0.0;
+        if (dscores)
+            for (int j = 0; j < L; ++j)
+                dscores[(size_t)b * L + j] = (j < nb) ? exp(s[j] - ms) / zs - exp(y[j] - my) / zy : 0.0;
+    }
+    return 0;
 }

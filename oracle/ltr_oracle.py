@@ -87,6 +87,39 @@ def pairwise_loss(kind, scores, relevance, n, sigma=1.0, need_grad=True):
     return loss, ds
 
 
+class tie_priorities:
+    """Context: rank with the reference's random tie-break given ONE drawn permutation --
+    `tie[j]` is document j's priority among equal scores (smaller ranks first).  Applies to
+    rank_by_score, dcg/ndcg, arp and the rankings inside the Lambda losses of this oracle."""
+
+    def __init__(self, tie):
+        self.tie = None if tie is None else np.ascontiguousarray(np.asarray(tie, dtype=np.int32))
+
+    def __enter__(self):
+        _load().oracle_set_tie(None if self.tie is None else _p(self.tie, ctypes.c_int32))
+        return self
+
+    def __exit__(self, *exc):
+        _load().oracle_set_tie(None)
+        return False
+
+
+def listwise_softmax(scores, relevance, n, need_grad=True):
+    """(loss[B], dscores[B,L] or None) of the listwise softmax cross-entropy -- parity unpinned,
+    the reference has no such loss (see ltr_oracle.c)."""
+    s = _bl(scores)
+    y = _bl(relevance)
+    nn = _n(n)
+    B, L = s.shape
+    loss = np.zeros(B, dtype=np.float64)
+    ds = np.zeros((B, L), dtype=np.float64) if need_grad else None
+    rc = _load().oracle_listwise_softmax(_p(s), _p(y), _p(nn, ctypes.c_int64), B, L, _p(loss),
+                                         _p(ds) if need_grad else None)
+    if rc != 0:
+        raise RuntimeError("oracle_listwise_softmax failed: %d" % rc)
+    return loss, ds
+
+
 def rank_by_score(scores, n):
     s = _bl(scores)
     nn = _n(n)

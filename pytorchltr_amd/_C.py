@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libltr_hip.so")
 HINGE, DCG_HINGE, LOGISTIC, ARP1, ARP2, NDCG1, NDCG2 = range(7)
 # enum ltr_label_dtype
 LABEL_I64, LABEL_F32, LABEL_I32 = 0, 1, 2
+ERR_TIMEOUT = -7
 # ltr_linear_fused_plan (include/ltr_hip.h)
 PLAN_NONE, PLAN_REGISTER_TILE, PLAN_CLUSTER, PLAN_GENERAL = 0, 1, 2, 3
 
@@ -25,16 +26,24 @@ SIGNATURES = {
     "ltr_version": (_i, []),
     "ltr_error_string": (ctypes.c_char_p, [_i]),
     "ltr_max_list_len": (_i, []),
+    "ltr_max_list_len_f64": (_i, []),
+    "ltr_device_status": (_i, [_i]),
+    "ltr_debug_force_timeout": (None, [_i]),
     "ltr_pairwise_loss_f32": (_i, [_i, _f, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "ltr_pairwise_loss_f32_cfg": (_i, [_i, _f, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     "ltr_pairwise_loss_workspace_bytes": (_sz, [_i, _i, _i]),
     "ltr_pairwise_loss_ws_f32": (_i, [_i, _f, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "ltr_scale_rows_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "ltr_scale_rows_uniform_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "ltr_pairwise_loss_f64": (_i, [_i, ctypes.c_double, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "ltr_scale_rows_f64": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "ltr_rank_by_score_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "ltr_dcg_f32": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ltr_arp_f32": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
+    "ltr_rank_by_score_tie_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "ltr_dcg_tie_f32": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ltr_arp_tie_f32": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    "ltr_listwise_softmax_f32": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "ltr_mask_padded_values_f32": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp]),
     "ltr_batch_pairs": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "ltr_plackettluce_keys_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
@@ -48,6 +57,7 @@ SIGNATURES = {
                                      _vp, _vp, _vp, _vp]),
     "ltr_linear_reduce_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "ltr_linear_reduce_loss_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "ltr_linear_reduce_accum_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "ltr_linear_scores_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ltr_linear_grad_workspace_bytes": (_sz, [_i, _i, _i]),
     "ltr_linear_grad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
@@ -126,6 +136,7 @@ def device_ctx(t):
 
 
 _max_len = None
+_max_len_f64 = None
 
 
 def max_list_len():
@@ -133,6 +144,23 @@ def max_list_len():
     if _max_len is None:
         _max_len = int(lib().ltr_max_list_len())
     return _max_len
+
+
+def max_list_len_f64():
+    global _max_len_f64
+    if _max_len_f64 is None:
+        _max_len_f64 = int(lib().ltr_max_list_len_f64())
+    return _max_len_f64
+
+
+def device_status(clear=True, synchronize=True):
+    """The sticky device status word (include/ltr_hip.h: ltr_device_status): raises RuntimeError if
+    a multi-workgroup kernel of an earlier launch gave up waiting for its partners (its outputs are
+    NaN-poisoned).  `synchronize` waits for the current device first, so the answer covers every
+    launch issued so far."""
+    if synchronize and torch.cuda.is_available():
+        torch.cuda.synchronize()
+    check(lib().ltr_device_status(1 if clear else 0))
 
 
 def require_device(t, what):

@@ -30,6 +30,43 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
 // ---------------------------------------------------------------------------------
+// Device status word.  The only kernels that can fail at run time are the ones whose workgroups
+// wait for each other (ltr_cluster.inc): a wait that gives up must not end as a silent NaN.  One
+// pinned, device-mapped host page per process holds a sticky status word; a kernel that gives up
+// stores LTR_ERR_TIMEOUT there (system-scope store, rare path), and the linear-scorer entry
+// points return it -- without any synchronisation: a host read of pinned memory -- on the NEXT
+// call; ltr_device_status() reads / clears it explicitly.  Allocated lazily outside stream capture;
+// until then (or when the allocation fails) the kernels only poison their outputs with NaN.
+// ---------------------------------------------------------------------------------
+struct StatusPage { int *host; int *dev; };
+inline StatusPage &status_page_ref() { static StatusPage sp = {nullptr, nullptr}; return sp; }
+inline int *status_device_ptr(hipStream_t stream)
+{
+    StatusPage &sp = status_page_ref();
+    if (sp.dev) return sp.dev;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    static bool tried = false;
+    if (tried) return nullptr;
+    tried = true;
+    void *h = nullptr, *d = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    for (int i = 0; i < 16; ++i) reinterpret_cast<volatile int *>(h)[i] = 0;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return nullptr; }
+    sp.host = reinterpret_cast<int *>(h);
+    sp.dev = reinterpret_cast<int *>(d);
+    return sp.dev;
+}
+inline int status_peek()
+{
+    const StatusPage &sp = status_page_ref();
+    return sp.host ? *reinterpret_cast<volatile int *>(sp.host) : 0;
+}
+
+// ---------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ float load_label(const void *rel, int dtype, size_t idx)
@@ -340,9 +377,10 @@ __device__ __forceinline__ unsigned long long rank_key(float v, int idx)
     return ((unsigned long long)(~asc) << 32) | (unsigned)idx;
 }
 
+// inv (LDS, may be null): the low key word is a tie priority, inv[priority] = document index.
 template <int E>
 __device__ __forceinline__ void sort_ranks(unsigned long long (&v)[E], int P, int nb, int *rank_out,
-                                           unsigned long long *xbuf)
+                                           unsigned long long *xbuf, const int *inv = nullptr)
 {
     const int tid = threadIdx.x;
     const int T = blockDim.x;
@@ -390,8 +428,11 @@ __device__ __forceinline__ void sort_ranks(unsigned long long (&v)[E], int P, in
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        const int idx = (int)(unsigned)v[e];
-        if (v[e] != ~0ull && idx < nb) rank_out[idx] = e * T + tid;
+        if (v[e] != ~0ull) {
+            const int low = (int)(unsigned)v[e];
+            const int idx = inv ? inv[low] : low;
+            if (idx < nb) rank_out[idx] = e * T + tid;
+        }
     }
 }
 
@@ -1166,6 +1207,86 @@ __global__ void scale_rows_vec4_kernel(const float4 *__restrict__ ds, const floa
     }
 }
 
+// the same with one upstream gradient for all rows (`.mean().backward()`: autograd hands over an
+// expanded scalar), read from device memory
+__global__ void scale_uniform_kernel(const float *__restrict__ ds, const float *__restrict__ go,
+                                     size_t total, float *__restrict__ out)
+{
+    const float g = go[0];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
+        out[i] = ds[i] * g;
+}
+
+__global__ void scale_uniform_vec4_kernel(const float4 *__restrict__ ds, const float *__restrict__ go,
+                                          size_t total4, float4 *__restrict__ out)
+{
+    const float g = go[0];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+        float4 v = ds[i];
+        v.x *= g; v.y *= g; v.z *= g; v.w *= g;
+        out[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Listwise softmax cross-entropy (ListNet top-one) -- named by the project brief, absent from the
+// reference (pytorchltr/loss/__init__.py:1-7): the specification is include/ltr_hip.h.
+//   loss = ln Z_s - sum_j P_y(j) (s_j - max s),  Z_s = sum_j exp(s_j - max s),  P_y = softmax(y)
+//   d loss / d s_j = exp(s_j - max s) / Z_s - P_y(j)
+// O(n) per query: one WAVE per query, four queries per workgroup, the row re-read from L1/L2 for
+// the three passes (max, sums, gradient) -- no LDS, no barriers.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
+    return v;
+}
+
+template <typename LabelT>
+__global__ void __launch_bounds__(256)
+listwise_softmax_kernel(const float *__restrict__ scores, const LabelT *__restrict__ rel,
+                        const int64_t *__restrict__ n, int B, int L, float *__restrict__ loss,
+                        float *__restrict__ dscores)
+{
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;                                   // wave-uniform
+    const int nb = clamp_n(n[b], L);
+    const size_t row = (size_t)b * L;
+    float ms = -INFINITY, my = -INFINITY;
+    for (int j = lane; j < nb; j += 64) {
+        ms = fmaxf(ms, scores[row + j]);
+        my = fmaxf(my, (float)rel[row + j]);
+    }
+    ms = wave_max(ms);
+    my = wave_max(my);
+    float zs = 0.f, zy = 0.f, dot = 0.f;
+    for (int j = lane; j < nb; j += 64) {
+        const float ds = scores[row + j] - ms;
+        const float ey = expf((float)rel[row + j] - my);
+        zs += expf(ds);
+        zy += ey;
+        dot += ey * ds;
+    }
+    zs = wave_sum(zs);
+    zy = wave_sum(zy);
+    dot = wave_sum(dot);
+    const float inv_zs = nb > 0 ? 1.0f / zs : 0.f;
+    const float inv_zy = nb > 0 ? 1.0f / zy : 0.f;
+    if (lane == 0) loss[b] = nb > 0 ? (logf(zs) - dot * inv_zy) : 0.f;
+    if (dscores != nullptr) {
+        for (int j = lane; j < L; j += 64) {
+            float g = 0.f;
+            if (j < nb)
+                g = expf(scores[row + j] - ms) * inv_zs - expf((float)rel[row + j] - my) * inv_zy;
+            dscores[row + j] = g;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // rank_by_score / dcg / ndcg / arp
 // ---------------------------------------------------------------------------------
@@ -1173,6 +1294,7 @@ struct MetricParams {
     const float *scores;
     const void *rel;
     const int64_t *n;
+    const int32_t *tie;   // (L) tie priorities (a permutation of 0..L-1) or null = index order
     void *out;
     int B, L;
     int rel_dtype;
@@ -1191,7 +1313,8 @@ __host__ __device__ inline size_t metric_lds_bytes(int L)
 __host__ __device__ inline size_t metric_lds_bytes_sort(int L)
 {
     const size_t L4 = (size_t)((L + 3) & ~3);
-    return 8 * L4 + 8 * L4 + 8 * (size_t)sort_pow2(L) + 32 * 4 + 64 * 4;
+    // ... + the inverse tie map int[L4] behind everything else
+    return 8 * L4 + 8 * L4 + 8 * (size_t)sort_pow2(L) + 32 * 4 + 64 * 4 + 4 * L4;
 }
 
 // Inclusive prefix sum of buf[0..L) in place (LDS).  Thread t owns a contiguous chunk.
@@ -1269,27 +1392,36 @@ metric_kernel(MetricParams p)
         unsigned long long *xbuf = reinterpret_cast<unsigned long long *>(curve);
         int Pq = 64;                                    // smallest power of two >= n of this query
         while (Pq < nb) Pq <<= 1;
+        // random tie-break: the low key word is the document's tie priority; the inverse map
+        // (priority -> document) sits behind the other arrays
+        int *invt = nullptr;
+        if (p.tie) {
+            invt = reinterpret_cast<int *>(smem + metric_lds_bytes_sort(L) - 4 * (size_t)L4);
+            for (int j = tid; j < L; j += T) invt[p.tie[j]] = j;
+            __syncthreads();
+        }
         unsigned long long v[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int i = e * T + tid;
-            v[e] = (i < nb) ? rank_key(sy[i].x, i) : ~0ull;
+            v[e] = (i < nb) ? rank_key(sy[i].x, p.tie ? p.tie[i] : i) : ~0ull;
         }
-        sort_ranks<E>(v, Pq, nb, rank_s, xbuf);
+        sort_ranks<E>(v, Pq, nb, rank_s, xbuf, invt);
         if (with_y) {
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const int i = e * T + tid;
-                v[e] = (i < nb) ? rank_key(sy[i].y, i) : ~0ull;
+                v[e] = (i < nb) ? rank_key(sy[i].y, p.tie ? p.tie[i] : i) : ~0ull;
             }
-            sort_ranks<E>(v, Pq, nb, rank_y, xbuf);
+            sort_ranks<E>(v, Pq, nb, rank_y, xbuf, invt);
         }
     } else {
         // counting rank on packed keys (see count_ranks_keyed); the keys live in the curve region
         ulonglong2 *keys = reinterpret_cast<ulonglong2 *>(curve);
         for (int k = tid; k < nb; k += T) {
             const float2 v = sy[k];
-            keys[k] = make_ulonglong2(rank_key(v.x, k), rank_key(v.y, k));
+            const int t = p.tie ? p.tie[k] : k;         // tie priority (random tie-break) or index
+            keys[k] = make_ulonglong2(rank_key(v.x, t), rank_key(v.y, t));
         }
         __syncthreads();
         if (with_y)
@@ -1773,6 +1905,16 @@ int ltr_version(void) { return LTR_VERSION; }
 
 int ltr_max_list_len(void) { return kMaxListLen; }
 
+int ltr_device_status(int clear)
+{
+    StatusPage &sp = status_page_ref();
+    if (!sp.host) return LTR_OK;
+    volatile int *w = reinterpret_cast<volatile int *>(sp.host);
+    const int v = *w;
+    if (clear) *w = 0;
+    return v;
+}
+
 const char *ltr_error_string(int code)
 {
     switch (code) {
@@ -1783,6 +1925,7 @@ const char *ltr_error_string(int code)
     case LTR_ERR_LIST_TOO_LONG: return "ltr: list_len exceeds ltr_max_list_len()";
     case LTR_ERR_WORKSPACE: return "ltr: workspace missing or too small";
     case LTR_ERR_CONFIG: return "ltr: invalid explicit launch configuration";
+    case LTR_ERR_TIMEOUT: return "ltr: a multi-workgroup kernel gave up waiting for its partners; the outputs of that launch are invalid (ltr_device_status(1) clears the flag)";
     default: break;
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);
@@ -1888,20 +2031,45 @@ int ltr_scale_rows_f32(const float *dscores, const float *grad_out, int B, int L
     return (int)hipGetLastError();
 }
 
-int ltr_rank_by_score_f32(const float *scores, const int64_t *n, int B, int L, int64_t *ranking,
-                          void *stream)
+int ltr_scale_rows_uniform_f32(const float *dscores, const float *grad_scalar, int B, int L,
+                               float *out, void *stream)
+{
+    if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
+    if (B == 0) return LTR_OK;
+    if (!dscores || !grad_scalar || !out) return LTR_ERR_NULL;
+    const size_t total = (size_t)B * L;
+    const bool vec = (total % 4 == 0) && (((uintptr_t)dscores | (uintptr_t)out) % 16 == 0);
+    if (vec)
+        hipLaunchKernelGGL(scale_uniform_vec4_kernel, dim3(grid_for(total / 4, 256)), dim3(256), 0,
+                           (hipStream_t)stream, (const float4 *)dscores, grad_scalar, total / 4,
+                           (float4 *)out);
+    else
+        hipLaunchKernelGGL(scale_uniform_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
+                           (hipStream_t)stream, dscores, grad_scalar, total, out);
+    return (int)hipGetLastError();
+}
+
+int ltr_rank_by_score_tie_f32(const float *scores, const int64_t *n, const int32_t *tie, int B, int L,
+                              int64_t *ranking, void *stream)
 {
     if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
     if (L > kMaxListLen) return LTR_ERR_LIST_TOO_LONG;
     if (B == 0) return LTR_OK;
     if (!scores || !n || !ranking) return LTR_ERR_NULL;
     MetricParams p{};
-    p.scores = scores; p.rel = nullptr; p.n = n; p.out = ranking; p.B = B; p.L = L;
+    p.scores = scores; p.rel = nullptr; p.n = n; p.tie = tie; p.out = ranking; p.B = B; p.L = L;
     return launch_metric<METRIC_RANK>(p, (hipStream_t)stream);
 }
 
-int ltr_dcg_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n, int B,
-                int L, int k, int use_exp, int normalize, float *out, void *stream)
+int ltr_rank_by_score_f32(const float *scores, const int64_t *n, int B, int L, int64_t *ranking,
+                          void *stream)
+{
+    return ltr_rank_by_score_tie_f32(scores, n, nullptr, B, L, ranking, stream);
+}
+
+int ltr_dcg_tie_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n,
+                    const int32_t *tie, int B, int L, int k, int use_exp, int normalize, float *out,
+                    void *stream)
 {
     if (bad_label_dtype(rel_dtype)) return LTR_ERR_KIND;
     if (B < 0 || L <= 0 || k < 0) return LTR_ERR_SHAPE;
@@ -1909,13 +2077,19 @@ int ltr_dcg_f32(const float *scores, const void *rel, int rel_dtype, const int64
     if (B == 0) return LTR_OK;
     if (!scores || !rel || !n || !out) return LTR_ERR_NULL;
     MetricParams p{};
-    p.scores = scores; p.rel = rel; p.n = n; p.out = out; p.B = B; p.L = L;
+    p.scores = scores; p.rel = rel; p.n = n; p.tie = tie; p.out = out; p.B = B; p.L = L;
     p.rel_dtype = rel_dtype; p.k = k; p.use_exp = use_exp; p.normalize = normalize;
     return launch_metric<METRIC_DCG>(p, (hipStream_t)stream);
 }
 
-int ltr_arp_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n, int B,
-                int L, float *out, void *stream)
+int ltr_dcg_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n, int B,
+                int L, int k, int use_exp, int normalize, float *out, void *stream)
+{
+    return ltr_dcg_tie_f32(scores, rel, rel_dtype, n, nullptr, B, L, k, use_exp, normalize, out, stream);
+}
+
+int ltr_arp_tie_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n,
+                    const int32_t *tie, int B, int L, float *out, void *stream)
 {
     if (bad_label_dtype(rel_dtype)) return LTR_ERR_KIND;
     if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
@@ -1923,9 +2097,36 @@ int ltr_arp_f32(const float *scores, const void *rel, int rel_dtype, const int64
     if (B == 0) return LTR_OK;
     if (!scores || !rel || !n || !out) return LTR_ERR_NULL;
     MetricParams p{};
-    p.scores = scores; p.rel = rel; p.n = n; p.out = out; p.B = B; p.L = L;
+    p.scores = scores; p.rel = rel; p.n = n; p.tie = tie; p.out = out; p.B = B; p.L = L;
     p.rel_dtype = rel_dtype;
     return launch_metric<METRIC_ARP>(p, (hipStream_t)stream);
+}
+
+int ltr_arp_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n, int B,
+                int L, float *out, void *stream)
+{
+    return ltr_arp_tie_f32(scores, rel, rel_dtype, n, nullptr, B, L, out, stream);
+}
+
+int ltr_listwise_softmax_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n,
+                             int B, int L, float *loss, float *dscores, void *stream)
+{
+    if (bad_label_dtype(rel_dtype)) return LTR_ERR_KIND;
+    if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
+    if (B == 0) return LTR_OK;
+    if (!scores || !rel || !n || !loss) return LTR_ERR_NULL;
+    const dim3 grid((unsigned)((B + 3) / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (rel_dtype == LTR_LABEL_I64)
+        hipLaunchKernelGGL((listwise_softmax_kernel<int64_t>), grid, block, 0, st, scores,
+                           (const int64_t *)rel, n, B, L, loss, dscores);
+    else if (rel_dtype == LTR_LABEL_F32)
+        hipLaunchKernelGGL((listwise_softmax_kernel<float>), grid, block, 0, st, scores,
+                           (const float *)rel, n, B, L, loss, dscores);
+    else
+        hipLaunchKernelGGL((listwise_softmax_kernel<int32_t>), grid, block, 0, st, scores,
+                           (const int32_t *)rel, n, B, L, loss, dscores);
+    return (int)hipGetLastError();
 }
 
 int ltr_mask_padded_values_f32(const float *xs, const int64_t *n, int B, int L, float mask_value,

@@ -2,6 +2,7 @@
 import torch as _torch
 
 from pytorchltr_amd import _C
+from pytorchltr_amd import _ties
 from pytorchltr_amd._prepare import prepare as _prepare
 
 
@@ -21,7 +22,8 @@ def arp(scores: _torch.FloatTensor, relevance: _torch.LongTensor,
     B, L = s.shape
     out = _torch.empty(B, dtype=_torch.float32, device=s.device)
     if B > 0:
+        tie = _ties.draw_priorities(L, s.device)      # random tie-break, as the reference (arp.py:32)
         with _C.device_ctx(s):
-            _C.check(_C.lib().ltr_arp_f32(_C.ptr(s), _C.ptr(r), _C.label_dtype(r), _C.ptr(nn),
-                                          B, L, _C.ptr(out), _C.stream_of(s)))
+            _C.check(_C.lib().ltr_arp_tie_f32(_C.ptr(s), _C.ptr(r), _C.label_dtype(r), _C.ptr(nn),
+                                              _C.ptr(tie), B, L, _C.ptr(out), _C.stream_of(s)))
     return out

@@ -2,13 +2,16 @@
 
 One kernel per call ranks each query by score (and, for NDCG, by label) with an in-LDS
 counting rank, applies gains and log2 discounts and either reduces to metric@k or prefix-sums
-the whole curve.  As in the reference, labels of padded documents are not masked.
+the whole curve.  As in the reference, labels of padded documents are not masked, and equal
+scores are ordered by a random permutation drawn per call (``pytorchltr_amd.utils.tie_breaking``
+selects the deterministic index order instead).
 """
 from typing import Optional
 
 import torch as _torch
 
 from pytorchltr_amd import _C
+from pytorchltr_amd import _ties
 from pytorchltr_amd._prepare import prepare as _prepare
 
 
@@ -29,10 +32,12 @@ def _run(scores, relevance, n, k, exp, normalize):
     kk = _cutoff(k, L)
     out = _torch.empty((B,) if kk > 0 else (B, L), dtype=_torch.float32, device=s.device)
     if B > 0:
+        # the reference ranks through rank_by_score with its global-RNG tie-break (dcg.py:85)
+        tie = _ties.draw_priorities(L, s.device)
         with _C.device_ctx(s):
-            _C.check(_C.lib().ltr_dcg_f32(_C.ptr(s), _C.ptr(r), _C.label_dtype(r), _C.ptr(nn),
-                                          B, L, kk, int(bool(exp)), int(normalize),
-                                          _C.ptr(out), _C.stream_of(s)))
+            _C.check(_C.lib().ltr_dcg_tie_f32(_C.ptr(s), _C.ptr(r), _C.label_dtype(r), _C.ptr(nn),
+                                              _C.ptr(tie), B, L, kk, int(bool(exp)), int(normalize),
+                                              _C.ptr(out), _C.stream_of(s)))
     return out
 
 

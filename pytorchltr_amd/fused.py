@@ -32,12 +32,58 @@ def _resolve_loss(loss):
 
 
 def _prepare_features(xs):
+    if xs.dtype is torch.float32 and xs.is_cuda and xs.dim() == 3 and xs.is_contiguous():
+        return xs                                   # the common case: nothing to do
     _C.require_device(xs, "xs")
     if xs.dim() != 3:
         raise ValueError("features must have shape (batch, list_size, features)")
     if xs.dtype != torch.float32:
         xs = xs.float()
     return xs.contiguous()
+
+
+def _flat_f32(t, count):
+    """A parameter as a contiguous fp32 vector of `count` elements (no copy in the common case)."""
+    if t.dtype is torch.float32 and t.is_contiguous() and t.numel() == count:
+        return t
+    return t.detach().reshape(count).float().contiguous()
+
+
+class _ShapeOnly:
+    def __init__(self, *shape):
+        self.shape = torch.Size(shape)
+
+
+def _labels_and_n(relevance, n, B, L, dev):
+    """relevance / n as the C ABI takes them; the generic normalisation only when needed."""
+    if (relevance.dtype in _LABEL_CODE and relevance.is_contiguous() and relevance.device == dev
+            and relevance.dim() in (2, 3) and relevance.shape[0] == B and relevance.shape[1] == L
+            and relevance.numel() == B * L):
+        r = relevance
+    else:
+        r = prepare_relevance(relevance, _ShapeOnly(B, L))
+        if r.device != dev:
+            raise RuntimeError("features and relevance must be on the same device")
+    if (n.dtype is torch.int64 and n.dim() == 1 and n.shape[0] == B and n.is_contiguous()
+            and n.device == dev):
+        nn = n
+    else:
+        nn = prepare_n(n, B)
+        if nn.device != dev:
+            raise RuntimeError("features and n must be on the same device")
+    return r, nn
+
+
+_LABEL_CODE = {torch.int64: _C.LABEL_I64, torch.float32: _C.LABEL_F32, torch.int32: _C.LABEL_I32}
+_linear_ws_cache = {}       # (B, L, F) -> ltr_linear_workspace_bytes
+
+
+def _linear_ws_bytes(B, L, F):
+    key = (B, L, F)
+    v = _linear_ws_cache.get(key)
+    if v is None:
+        v = _linear_ws_cache[key] = max(int(_C.lib().ltr_linear_workspace_bytes(B, L, F)), 4)
+    return v
 
 
 class _LinearLossFunction(torch.autograd.Function):
@@ -47,22 +93,25 @@ class _LinearLossFunction(torch.autograd.Function):
         B, L, F = X.shape
         if weight.numel() != F:
             raise ValueError("weight has %d elements, features have %d" % (weight.numel(), F))
-        W = weight.detach().reshape(F).float().contiguous()
-        bvec = None if bias is None else bias.detach().reshape(1).float().contiguous()
-        r = prepare_relevance(relevance, X[:, :, 0])
-        nn = prepare_n(n, B)
-        loss = torch.empty(B, dtype=torch.float32, device=X.device)
-        ws_bytes = _C.lib().ltr_linear_workspace_bytes(B, L, F)
-        ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=X.device)
-        part = ws[:(F + 1) * B].view(F + 1, B)        # (F+1, B) partials; tail = kernel scratch
-        scores = torch.empty(B, L, dtype=torch.float32, device=X.device) if want_scores else None
+        dev = X.device
+        W = _flat_f32(weight, F)
+        bvec = None if bias is None else _flat_f32(bias, 1)
+        r, nn = _labels_and_n(relevance, n, B, L, dev)
+        loss = torch.empty(B, dtype=torch.float32, device=dev)
+        # (F+1, B) partials, then the kernel's scratch
+        ws = torch.empty(_linear_ws_bytes(B, L, F) // 4, dtype=torch.float32, device=dev)
+        scores = torch.empty((B, L), dtype=torch.float32, device=dev) if want_scores else None
         if B > 0:
             with _C.device_ctx(X):
-                _C.check(_C.lib().ltr_linear_partials_f32(
-                    kind, float(sigma), _C.ptr(X), _C.ptr(W), _C.ptr(bvec), _C.ptr(r),
-                    _C.label_dtype(r), _C.ptr(nn), B, L, F, _C.ptr(loss), _C.ptr(scores),
-                    _C.ptr(part), _C.stream_of(X)))
-        ctx.save_for_backward(part)
+                rc = _C.lib().ltr_linear_partials_f32(
+                    kind, float(sigma), X.data_ptr(), W.data_ptr(),
+                    None if bvec is None else bvec.data_ptr(), r.data_ptr(), _LABEL_CODE[r.dtype],
+                    nn.data_ptr(), B, L, F, loss.data_ptr(),
+                    None if scores is None else scores.data_ptr(), ws.data_ptr(), _C.stream_of(X))
+                if rc != 0:
+                    _C.check(rc)
+        ctx.save_for_backward(ws)
+        ctx.dims = (B, F)
         ctx.w_shape = weight.shape
         ctx.has_bias = bias is not None
         if want_scores:
@@ -73,17 +122,22 @@ class _LinearLossFunction(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_loss, *unused):
-        (part,) = ctx.saved_tensors
-        F1, B = part.shape
-        F = F1 - 1
-        go = grad_loss.reshape(B).float().contiguous()
-        dW = torch.empty(F, dtype=torch.float32, device=part.device)
-        db = torch.empty(1, dtype=torch.float32, device=part.device)
-        with _C.device_ctx(part):
-            _C.check(_C.lib().ltr_linear_reduce_f32(_C.ptr(part), _C.ptr(go), B, F, _C.ptr(dW),
-                                                    _C.ptr(db), _C.stream_of(part)))
-        return (None, dW.reshape(ctx.w_shape), db if ctx.has_bias else None,
-                None, None, None, None, None)
+        (ws,) = ctx.saved_tensors
+        B, F = ctx.dims
+        go = grad_loss
+        if go.dtype is not torch.float32 or go.dim() != 1 or not go.is_contiguous():
+            go = go.reshape(B).float().contiguous()
+        dW = torch.empty(ctx.w_shape, dtype=torch.float32, device=ws.device)
+        db = torch.empty(1, dtype=torch.float32, device=ws.device)
+        with _C.device_ctx(ws):
+            rc = _C.lib().ltr_linear_reduce_f32(ws.data_ptr(), go.data_ptr(), B, F, dW.data_ptr(),
+                                                db.data_ptr(), _C.stream_of(ws))
+            if rc != 0:
+                _C.check(rc)
+        return (None, dW, db if ctx.has_bias else None, None, None, None, None, None)
+
+
+_pieces_cache = {}
 
 
 class FusedLinearLoss(torch.nn.Module):
@@ -108,7 +162,7 @@ class FusedLinearLoss(torch.nn.Module):
             torch.nn.init.uniform_(self.bias, -bound, bound)
 
     def forward(self, xs, relevance, n, return_scores=False):
-        if xs.dim() == 3 and xs.is_cuda and self._prefer_pieces(xs.shape[0], xs.shape[1]):
+        if xs.dim() == 3 and xs.is_cuda and self._pieces_cached(xs.shape[0], xs.shape[1]):
             # a few long lists: one workgroup per query cannot fill the GPU; the balanced pieces
             # (streaming scorer, split-query loss, streaming weight gradient) are faster
             from ._autograd import PairwiseLossFunction
@@ -117,6 +171,13 @@ class FusedLinearLoss(torch.nn.Module):
             return (loss, scores.detach().squeeze(-1)) if return_scores else loss
         return _LinearLossFunction.apply(xs, self.weight, self.bias, relevance, n, self.kind,
                                          self.sigma, bool(return_scores))
+
+    def _pieces_cached(self, B, L):
+        key = (self.kind, B, L, self.in_features)
+        v = _pieces_cache.get(key)
+        if v is None:
+            v = _pieces_cache[key] = bool(self._prefer_pieces(B, L))
+        return v
 
     def _prefer_pieces(self, B, L):
         # measured on MI355X, fused kernel -> pieces, us (B x L x F; hinge / logistic / LambdaNDCG2):
@@ -146,10 +207,9 @@ def linear_loss_step(xs, weight, bias, relevance, n, loss="hinge", grad_out=None
     kind, sigma = _resolve_loss(loss)
     X = _prepare_features(xs)
     B, L, F = X.shape
-    W = weight.detach().reshape(F).float().contiguous()
-    bvec = None if bias is None else bias.detach().reshape(1).float().contiguous()
-    r = prepare_relevance(relevance, X[:, :, 0])
-    nn = prepare_n(n, B)
+    W = _flat_f32(weight, F)
+    bvec = None if bias is None else _flat_f32(bias, 1)
+    r, nn = _labels_and_n(relevance, n, B, L, X.device)
     lossv = torch.empty(B, dtype=torch.float32, device=X.device)
     dW = torch.empty(F, dtype=torch.float32, device=X.device)
     db = torch.empty(1, dtype=torch.float32, device=X.device)

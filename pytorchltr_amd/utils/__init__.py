@@ -7,5 +7,7 @@ from pytorchltr_amd.utils.tensor_operations import (
     tiebreak_argsort,
 )
 
+from pytorchltr_amd._ties import get_tie_breaking, set_tie_breaking, tie_breaking
+
 __all__ = ["mask_padded_values", "tiebreak_argsort", "rank_by_score", "rank_by_plackettluce",
-           "batch_pairs"]
+           "batch_pairs", "tie_breaking", "set_tie_breaking", "get_tie_breaking"]

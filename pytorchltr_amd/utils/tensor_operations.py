@@ -8,6 +8,7 @@ from typing import Optional
 import torch as _torch
 
 from pytorchltr_amd import _C
+from pytorchltr_amd import _ties
 from pytorchltr_amd._prepare import as_2d as _as_2d
 from pytorchltr_amd._prepare import prepare_n as _prepare_n
 from pytorchltr_amd._prepare import prepare_scores_f32 as _prepare_scores
@@ -41,13 +42,14 @@ def mask_padded_values(xs: _torch.FloatTensor, n: _torch.LongTensor,
     return out if xs.dtype == _torch.float32 else out.to(xs.dtype)
 
 
-def _rank(scores2d, nn):
+def _rank(scores2d, nn, tie=None):
     B, L = scores2d.shape
     ranking = _torch.empty(B, L, dtype=_torch.int64, device=scores2d.device)
     if B > 0:
         with _C.device_ctx(scores2d):
-            _C.check(_C.lib().ltr_rank_by_score_f32(
-                _C.ptr(scores2d), _C.ptr(nn), B, L, _C.ptr(ranking), _C.stream_of(scores2d)))
+            _C.check(_C.lib().ltr_rank_by_score_tie_f32(
+                _C.ptr(scores2d), _C.ptr(nn), _C.ptr(tie), B, L, _C.ptr(ranking),
+                _C.stream_of(scores2d)))
     return ranking
 
 
@@ -57,13 +59,15 @@ def tiebreak_argsort(
         generator: Optional[_torch.Generator] = None) -> _torch.LongTensor:
     """Per-row argsort (reference :29-45).
 
-    Deviation: ties are broken by column index (deterministic) instead of a random
-    permutation; `generator` is accepted for signature compatibility and ignored."""
+    Ties are broken like the reference does: by one random permutation per call, shared by all
+    rows, drawn from `generator` (or the default generator of the tensor's device).  Under
+    ``pytorchltr_amd.utils.tie_breaking("index")`` and without a generator, ties fall back to
+    column order (deterministic)."""
     s = _prepare_scores(x)
     if not descending:
         s = -s
     nn = _torch.full((s.shape[0],), s.shape[1], dtype=_torch.int64, device=s.device)
-    return _rank(s, nn)
+    return _rank(s, nn, _ties.draw_priorities(s.shape[1], s.device, generator))
 
 
 def rank_by_score(
@@ -71,13 +75,14 @@ def rank_by_score(
         n: _torch.LongTensor,
         generator: Optional[_torch.Generator] = None) -> _torch.LongTensor:
     """Indices that sort each row by decreasing score, padded documents last (reference
-    :48-64).  Ties by index; the padded tail comes out in index order."""
+    :48-64).  Ties among real documents: random permutation per call (see tiebreak_argsort);
+    the padded tail comes out in index order."""
     s = _prepare_scores(scores)
     nn = _prepare_n(n, s.shape[0])
     max_l = _C.max_list_len()
     if s.shape[1] > max_l:
         raise ValueError("list_size %d exceeds the supported maximum %d" % (s.shape[1], max_l))
-    return _rank(s, nn)
+    return _rank(s, nn, _ties.draw_priorities(s.shape[1], s.device, generator))
 
 
 def _plackettluce_from_uniform(scores, n, uniform):
@@ -92,7 +97,7 @@ def _plackettluce_from_uniform(scores, n, uniform):
         with _C.device_ctx(s):
             _C.check(_C.lib().ltr_plackettluce_keys_f32(_C.ptr(s), _C.ptr(nn), _C.ptr(u), B, L,
                                                         _C.ptr(keys), _C.stream_of(s)))
-    return _rank(keys, nn)
+    return _rank(keys, nn)          # continuous keys: ties have probability ~0, index order
 
 
 def rank_by_plackettluce(
