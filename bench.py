@@ -12,21 +12,33 @@ batch (examples/01-basic-usage.py:70-75):
 
     loss = loss_fn(Linear(136, 1)(xs), ys, n).mean();  loss.backward()
 
-computed by the fused HIP path (scores -> PairwiseHingeLoss -> d/dW, d/db), inputs resident in
-HBM.  N > 1: one process per GPU, every rank owns its own B queries (weak scaling; queries are
-independent, no data-path collective) and the scorer gradients + (loss sum, count) are
-all-reduced in one RCCL bucket per step.
+computed by the fused HIP path (scores -> PairwiseHingeLoss -> d/dW, d/db) through the C ABI,
+launched EAGERLY (no hipGraph in `value`), inputs resident in HBM.
 
-Prints ONE JSON line on rank 0.  The same line carries
-  roofline      the dominant kernel (fused scorer+loss) timed live with HIP events,
-                algorithmic bytes / launch duration against 8 TB/s HBM3E;
-  cpu_baseline  the materialising CPU port of the reference path (oracle/materialized_torch.py)
-                timed on this box's host cores (rank 0, N=1 only);
-  extra         loss-only drop-in numbers, eager vs hipGraph, per-kernel times.
+Cold working set.  Consecutive steps take DIFFERENT batches: NBUF distinct synthetic batches whose
+feature tensors total more than the 256 MiB Infinity Cache are visited in rotation, so every step
+streams its features from HBM (a single 71 MB batch re-read every step would sit in the cache and
+flatter the roofline).  `roofline.frac` is computed on the bytes a launch MUST move -- only the
+n[b] real rows of every query are read -- next to the padded-formula figure of SURVEY.md 8(d);
+`roofline.full_lists` is the n == list_len twin, where both figures coincide.
+
+Timing.  The timed region holds max(K, enough steps for >= 50 ms) steps, bracketed by barrier +
+synchronize; it is repeated 5 times and the MEDIAN repeat is reported (max over ranks per repeat).
+
+N > 1: one process per GPU, queries are independent units -> no data-path collective.  Weak
+scaling by default (every rank owns its own B queries per step); `--shard` splits BASELINE's global
+batch over the ranks instead (C4: 32 queries / GPU at N = 8).  The only exchange is the scorer
+gradient: each rank accumulates `--accum` (default 8) micro-batch steps into one bucket
+[dW (F) | db | loss_sum | count] in HBM (reduce kernel with accumulate) and all-reduces it ONCE per
+`accum` steps over RCCL -- gradient accumulation, stated in config.allreduce_every.
+
+Prints ONE JSON line on rank 0 (metric, value, ..., roofline, cpu_baseline, extra).
 """
 import argparse
 import json
+import math
 import os
+import subprocess
 import sys
 import time
 
@@ -36,7 +48,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 achievable
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 achievable
+CU_COUNT = 256
+CLOCK_HZ = 2.4e9            # max shader clock (MI355X_MICROARCH.md)
+VALU_ISSUE_PER_CYCLE = 256  # wave-instructions per cycle the chip retires at 4 cycles per wave64
+                            # VALU instruction and SIMD (measured: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU
+                            # = 1.00 quad-cycle, profiles/r01_c2_sq.txt): 1024 SIMDs / 4
+L3_BYTES = 256 * 2 ** 20
 
 WORKLOADS = {
     # name: (B, L, F, loss kind)   -- BASELINE.json configs
@@ -45,6 +63,7 @@ WORKLOADS = {
     "c4": (256, 1000, 220, "dcg_hinge"),
     "c5": (512, 512, 700, "hinge"),
 }
+PLAN_NAMES = {1: "linear_regtile_kernel", 2: "linear_cluster_kernel", 3: "linear_pairwise_kernel"}
 
 
 def synth(B, L, F, seed, device):
@@ -57,68 +76,57 @@ def synth(B, L, F, seed, device):
     return scores.to(device), relevance.to(device), n.to(device), X.to(device)
 
 
-def fused_kernel_name(kind_id, B, L, F):
-    """Which kernel ltr_linear_partials_f32 dispatches to for this shape (asks the library)."""
-    from pytorchltr_amd import _C
-    plan = _C.lib().ltr_linear_fused_plan(kind_id, B, L, F)
-    return {_C.PLAN_REGISTER_TILE: "linear_regtile_kernel", _C.PLAN_CLUSTER: "linear_cluster_kernel",
-            _C.PLAN_GENERAL: "linear_pairwise_kernel"}.get(plan, "?")
+def nbuf_for(B, L, F):
+    """Distinct batches in rotation: their feature tensors together exceed the Infinity Cache."""
+    xbytes = 4 * B * L * F
+    return int(min(8, max(2, math.ceil(1.25 * L3_BYTES / xbytes))))
+
+
+def make_batches(B, L, F, nbuf, seed0, dev, full=False):
+    out = []
+    for i in range(nbuf):
+        scores, rel, n, X = synth(B, L, F, seed0 + i, dev)
+        if full:
+            n = torch.full_like(n, L)
+        out.append({"scores": scores, "rel": rel, "n": n, "X": X,
+                    "rows": int(n.clamp(max=L).sum())})
+    return out
+
+
+def moved_bytes(batches, B, L, F):
+    """Bytes one fused launch must move, averaged over the batches in rotation: the n[b] real rows
+    (features 4F + int64 label 8 each), n 8 B per query, W/bias, loss 4 B and the (F+1) partials
+    per query."""
+    rows = sum(b["rows"] for b in batches) / float(len(batches))
+    return rows * (4 * F + 8) + B * 8 + 4 * (F + 1) + B * 4 + 4 * (F + 1) * B
+
+
+def padded_bytes(B, L, F):
+    """algorithmic bytes per query of the fused step, padded formula."""
+    return B * (4 * L * F + 8 * L + 8 + 4 + 4 * (F + 1)) + 4 * (F + 1)
 
 
 def time_events(fn, iters):
-    """Per-launch duration (us) of fn() with ONE HIP event pair per launch, on the stream the
-    kernels are launched on (torch's current stream).  Includes the event-record overhead
-    (~4-5 us on this stack), so it is an upper bound; see time_launches for the figure used."""
+    """Per-launch duration (us) of fn() with ONE HIP event pair per launch on torch's current
+    stream (the stream the kernels are launched on).  Includes the event-record overhead
+    (~4-5 us on this stack): an upper bound, reported next to the graph-batched figure."""
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
     torch.cuda.synchronize()
     for i in range(iters):
         starts[i].record()
-        fn()
+        fn(i)
         ends[i].record()
     torch.cuda.synchronize()
     per = sorted(s.elapsed_time(e) * 1e3 for s, e in zip(starts, ends))
     return sum(per) / len(per), per[len(per) // 2], per[0]
 
 
-def time_launches(fn, per_graph=20, replays=10):
-    """Average launch duration (us): `per_graph` back-to-back launches of fn() captured into a
-    hipGraph, replayed `replays` times between ONE HIP event pair on the launch stream; the
-    average therefore contains the kernel plus its dependent-launch boundary, not host or event
-    overhead.  Falls back to eager back-to-back launches if capture is unavailable."""
-    def many():
-        for _ in range(per_graph):
-            fn()
-    replay = try_graph(many, warm=1)
-    run = replay if replay is not None else many
-    run()
-    torch.cuda.synchronize()
-    start = torch.cuda.Event(enable_timing=True)
-    end = torch.cuda.Event(enable_timing=True)
-    start.record()
-    for _ in range(replays):
-        run()
-    end.record()
-    torch.cuda.synchronize()
-    return start.elapsed_time(end) * 1e3 / (per_graph * replays), replay is not None
-
-
-def time_wall(fn, steps, barrier):
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        fn()
-    torch.cuda.synchronize()
-    barrier()
-    return time.perf_counter() - t0
-
-
 GRAPHS_OK = True     # cleared when a process group exists (see main)
 
 
-def try_graph(step, warm=3):
-    """Capture `step` (forward + backward) into a hipGraph; returns replay fn or None."""
+def try_graph(step, warm=2):
+    """Capture `step()` into a hipGraph; returns the replay function or None."""
     if not GRAPHS_OK:
         return None
     try:
@@ -142,16 +150,167 @@ def try_graph(step, warm=3):
         return None
 
 
-def mlp_extra(kind, X, relevance, n, no_graph):
+def time_launches(fn, nbuf, rounds=4, replays=10):
+    """Average launch duration (us) of fn(i), i cycling over the `nbuf` batches: rounds*nbuf
+    back-to-back launches captured into a hipGraph, replayed `replays` times between ONE HIP event
+    pair on the launch stream -- kernel + dependent-launch boundary, no host or event overhead.
+    Eager back-to-back launches if capture is unavailable."""
+    count = rounds * nbuf
+
+    def many():
+        for i in range(count):
+            fn(i)
+    replay = try_graph(many, warm=1)
+    run = replay if replay is not None else many
+    run()
+    torch.cuda.synchronize()
+    start = torch.cuda.Event(enable_timing=True)
+    end = torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(replays):
+        run()
+    end.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(end) * 1e3 / (count * replays), replay is not None
+
+
+def time_region(fn, steps, barrier, repeats=5, reduce_max=None):
+    """`repeats` timed regions of `steps` calls of fn(i), each bracketed by barrier + synchronize;
+    returns the list of elapsed seconds (max over ranks when reduce_max is given)."""
+    out = []
+    k = 0
+    for _ in range(repeats):
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _i in range(steps):
+            fn(k)
+            k += 1
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        if reduce_max is not None:
+            dt = reduce_max(dt)
+        out.append(dt)
+    return out
+
+
+def median(xs):
+    s = sorted(xs)
+    return s[len(s) // 2]
+
+
+def bucket_views(flat, F):
+    """The one all-reduced bucket of a step, (F + 3) floats: [dW (F) | db | loss_sum | count]."""
+    return flat[:F], flat[F:F + 1], flat[F + 1:F + 2], flat[F + 2:F + 3]
+
+
+class FusedStep:
+    """The step through the C ABI: ltr_linear_partials_f32 + ltr_linear_reduce_accum_f32, writing
+    the bucket [dW | db | loss_sum | count] (bucket_views)."""
+
+    def __init__(self, kind, B, L, F, dev, n_gpus=1, seed=0):
+        from pytorchltr_amd import _C
+        self._C = _C
+        self.lib = _C.lib()
+        self.kind_id = getattr(_C, kind.upper())
+        self.B, self.L, self.F = B, L, F
+        g = torch.Generator().manual_seed(seed)
+        bound = 1.0 / math.sqrt(F)
+        self.W = ((torch.rand(F, generator=g) * 2 - 1) * bound).to(dev)
+        self.bias = ((torch.rand(1, generator=g) * 2 - 1) * bound).to(dev)
+        self.lossv = torch.empty(B, device=dev)
+        self.ws_bytes = self.lib.ltr_linear_workspace_bytes(B, L, F)
+        self.part = torch.empty(self.ws_bytes // 4, device=dev)
+        self.flat = torch.zeros(F + 3, device=dev)
+        self.flat[F + 2] = float(B)
+        # uniform upstream gradient 1/(B*N): after the SUM all-reduce the bucket holds the gradient
+        # of the GLOBAL mean loss -- what `.mean().backward()` gives on the unsharded batch
+        self.go = torch.full((B,), 1.0 / (B * n_gpus), device=dev)
+        self.plan = PLAN_NAMES.get(self.lib.ltr_linear_fused_plan(self.kind_id, B, L, F), "?")
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def kernel(self, batch):
+        self._C.check(self.lib.ltr_linear_partials_f32(
+            self.kind_id, 1.0, batch["X"].data_ptr(), self.W.data_ptr(), self.bias.data_ptr(),
+            batch["rel"].data_ptr(), self._C.LABEL_I64, batch["n"].data_ptr(), self.B, self.L, self.F,
+            self.lossv.data_ptr(), None, self.part.data_ptr(), self._stream()))
+
+    def reduce(self, accumulate=False):
+        fp = self.flat.data_ptr()
+        self._C.check(self.lib.ltr_linear_reduce_accum_f32(
+            self.part.data_ptr(), self.go.data_ptr(), self.lossv.data_ptr(), self.B, self.F, fp,
+            fp + 4 * self.F, fp + 4 * (self.F + 1), 1 if accumulate else 0, self._stream()))
+
+    def step(self, batch, accumulate=False):
+        self.kernel(batch)
+        self.reduce(accumulate)
+
+
+def pmc_record(workload):
+    """PMC-derived per-launch figures of the workload's kernels (profiles/pmc_<workload>.json,
+    written by scripts/pmc_to_json.py from separate rocprofv3 --pmc passes of this command)."""
+    path = os.path.join(ROOT, "profiles", "pmc_%s.json" % workload)
+    if os.path.exists(path):
+        with open(path) as fh:
+            return json.load(fh)
+    return {}
+
+
+def valu_frac(valu_insts, us):
+    if not valu_insts or not us:
+        return None
+    return valu_insts / (VALU_ISSUE_PER_CYCLE * CLOCK_HZ * us * 1e-6)
+
+
+def measure_config(name, B, L, F, kind, dev, seed0, full=False, events=False, label=None):
+    """Cold (rotating batches) timing of the fused step and its dominant kernel for one shape."""
+    nbuf = nbuf_for(B, L, F)
+    batches = make_batches(B, L, F, nbuf, seed0, dev, full=full)
+    fs = FusedStep(kind, B, L, F, dev)
+    for i in range(2 * nbuf):
+        fs.step(batches[i % nbuf])
+    torch.cuda.synchronize()
+    k_us, graphed = time_launches(lambda i: fs.kernel(batches[i % nbuf]), nbuf)
+    s_us, _ = time_launches(lambda i: fs.step(batches[i % nbuf]), nbuf)
+    moved = moved_bytes(batches, B, L, F)
+    padded = padded_bytes(B, L, F)
+    pmc = pmc_record(name).get(fs.plan, {}) if not full else {}
+    res = {
+        "workload": label or "%s: Linear(%d,1) + %s, B=%d, list_len=%d, %s" % (
+            name, F, kind, B, L, "n == list_len" if full else "n~U[1,%d]" % L),
+        "plan": fs.plan, "batches_in_rotation": nbuf,
+        "rotating_feature_bytes": nbuf * 4 * B * L * F,
+        "kernel_us": k_us, "step_us": s_us, "step_queries_per_s": B / (s_us * 1e-6),
+        "timing": "HIP events around %s back-to-back launches over %d rotating batches" % (
+            "hipGraph-replayed" if graphed else "eager", nbuf),
+        "moved_bytes_per_launch": moved, "padded_formula_bytes_per_launch": padded,
+        "moved_GBs": moved / (k_us * 1e-6) / 1e9, "frac_moved": moved / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+        "frac_padded_formula": padded / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+        "traffic": pmc.get("hbm_bytes_per_launch"),
+        "valu_issue_frac": valu_frac(pmc.get("valu_insts_per_launch"), k_us),
+    }
+    if events:
+        avg, med, mn = time_events(lambda i: fs.kernel(batches[i % nbuf]), 100)
+        res["kernel_us_single_launch_event_pair"] = {"avg": avg, "median": med, "min": mn}
+    return res, fs, batches
+
+
+def mlp_extra(kind, batches, no_graph):
     """the guide's 136-50-10-1 ReLU MLP + loss + backward as one fused MFMA step
     (ltr_mlp_pairwise_f32), next to the same step written with torch layers + the HIP loss module."""
     from pytorchltr_amd import _C, fused
     from pytorchltr_amd import loss as L_
-    B, L, F = X.shape
+    X0 = batches[0]["X"]
+    B, L, F = X0.shape
     H1, H2 = 50, 10
     if not fused.mlp_supported(L, F, H1, H2):
         return None
-    dev = X.device
+    dev = X0.device
+    nbuf = len(batches)
     torch.manual_seed(0)
     m = fused.FusedMLPLoss(F, kind, hidden=(H1, H2)).to(dev)
     lib = _C.lib()
@@ -165,19 +324,21 @@ def mlp_extra(kind, X, relevance, n, no_graph):
                                                 m.l3.weight, m.l3.bias)]
     kind_id = getattr(_C, kind.upper())
 
-    def launch():
+    def launch(i):
+        b = batches[i % nbuf]
         _C.check(lib.ltr_mlp_pairwise_f32(
-            kind_id, 1.0, X.data_ptr(), *[p.data_ptr() for p in params], relevance.data_ptr(),
-            _C.LABEL_I64, n.data_ptr(), None, B, L, F, H1, H2, lossv.data_ptr(), None,
+            kind_id, 1.0, b["X"].data_ptr(), *[p.data_ptr() for p in params], b["rel"].data_ptr(),
+            _C.LABEL_I64, b["n"].data_ptr(), None, B, L, F, H1, H2, lossv.data_ptr(), None,
             grads.data_ptr(), lsum.data_ptr(), ws.data_ptr(), ws_bytes,
             torch.cuda.current_stream().cuda_stream))
 
-    for _ in range(5):
-        launch()
-    us, graphed = time_launches(launch, per_graph=10, replays=10)
-    docs = int(n.clamp(max=L).sum())
+    for i in range(nbuf):
+        launch(i)
+    us, _ = time_launches(launch, nbuf, rounds=2, replays=10)
+    docs = sum(b["rows"] for b in batches) / float(nbuf)
     flops_per_doc = 2 * (F * H1 + H1 * H2 + H2) + 2 * (F * H1 + 2 * H1 * H2 + H2)   # fwd + bwd, no dX
-    out = {"step": "MLP %d-%d-%d-1 + %s fwd+bwd (2 launches: mlp_pairwise_kernel + mlp_reduce_kernel)" % (F, H1, H2, kind),
+    out = {"step": "MLP %d-%d-%d-1 + %s fwd+bwd (2 launches: mlp_pairwise_kernel + mlp_reduce_kernel), "
+                   "%d rotating batches" % (F, H1, H2, kind, nbuf),
            "us_per_step": us, "queries_per_s": B / (us * 1e-6),
            "useful_TFLOPs": docs * flops_per_doc / (us * 1e-6) / 1e12,
            "f32_mfma_peak_TFLOPs": 157.3,
@@ -186,18 +347,20 @@ def mlp_extra(kind, X, relevance, n, no_graph):
                "logistic": L_.PairwiseLogisticLoss, "arp1": L_.LambdaARPLoss1, "arp2": L_.LambdaARPLoss2,
                "ndcg1": L_.LambdaNDCGLoss1, "ndcg2": L_.LambdaNDCGLoss2}[kind]()
     ps = list(m.parameters())
+    b0 = batches[0]
 
     def unfused():
         for p_ in ps:
             p_.grad = None
-        loss_fn(m.score(X), relevance, n).mean().backward()
-    for _ in range(5):
+        loss_fn(m.score(b0["X"]), b0["rel"], b0["n"]).mean().backward()
+    for _ in range(3):
         unfused()
-    res = {"eager_us": time_wall(unfused, 50, lambda: None) / 50 * 1e6}
-    rp = None if no_graph else try_graph(unfused)
-    if rp is not None:
-        res["hipgraph_us"] = time_wall(rp, 100, lambda: None) / 100 * 1e6
-    out["unfused_torch_layers_plus_loss_module"] = res
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(30):
+        unfused()
+    torch.cuda.synchronize()
+    out["unfused_torch_layers_plus_loss_module_eager_us"] = (time.perf_counter() - t0) / 30 * 1e6
     return out
 
 
@@ -246,16 +409,63 @@ def cpu_baseline(kind, B, L, F, reps=5):
     }
 
 
+def allreduce_probe():
+    """Internal (--allreduce-probe): one rank, RCCL process group forced; times the eager
+    all-reduce of the (F+3)-float bucket and the step with it.  Printed as one JSON line."""
+    import torch.distributed as dist
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    B, L, F, kind = WORKLOADS["c2"]
+    batches = make_batches(B, L, F, 2, 500, dev)
+    fs = FusedStep(kind, B, L, F, dev)
+    for i in range(20):
+        fs.step(batches[i % 2])
+        dist.all_reduce(fs.flat)
+    torch.cuda.synchronize()
+    out = {}
+    t0 = time.perf_counter()
+    for i in range(500):
+        dist.all_reduce(fs.flat)
+    torch.cuda.synchronize()
+    out["allreduce_only_us"] = (time.perf_counter() - t0) / 500 * 1e6
+    for accum in (1, 8):
+        t0 = time.perf_counter()
+        for i in range(800):
+            fs.step(batches[i % 2], accumulate=(i % accum) != 0)
+            if i % accum == accum - 1:
+                dist.all_reduce(fs.flat)
+        torch.cuda.synchronize()
+        out["step_with_allreduce_every_%d_us" % accum] = (time.perf_counter() - t0) / 800 * 1e6
+    t0 = time.perf_counter()
+    for i in range(800):
+        fs.step(batches[i % 2])
+    torch.cuda.synchronize()
+    out["step_without_allreduce_us"] = (time.perf_counter() - t0) / 800 * 1e6
+    dist.destroy_process_group()
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-graph", action="store_true", help="time the eager autograd path only")
+    ap.add_argument("--shard", action="store_true",
+                    help="strong scaling: BASELINE's global batch split over the ranks (default: weak, B per rank)")
+    ap.add_argument("--accum", type=int, default=8,
+                    help="N > 1: micro-batch steps accumulated per gradient all-reduce")
+    ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replay figures")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--full-lists", action="store_true", help="n == list_len for every query")
+    ap.add_argument("--no-extra", action="store_true", help="only the headline step + roofline")
+    ap.add_argument("--full-lists", action="store_true", help="n == list_len for every query in the timed step")
+    ap.add_argument("--allreduce-probe", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.allreduce_probe:
+        return allreduce_probe()
 
     # stdout carries exactly ONE line, the JSON result: RCCL prints a version banner to stdout when
     # a communicator is created, and other libraries may chat too -- send file descriptor 1 to
@@ -281,211 +491,129 @@ def main():
     if dist is not None:
         # ProcessGroupNCCL's watchdog thread polls HIP events; an event query while another
         # thread is capturing aborts the process ("operation not permitted when stream is
-        # capturing").  With a process group alive, launch eagerly -- the direct C-ABI step is
-        # host-cheap (3 launches + 1 collective) and was as fast as graph replay at N=1.
+        # capturing").  With a process group alive everything is launched eagerly.
         global GRAPHS_OK
-        GRAPHS_OK = os.environ.get("LTR_BENCH_DIST_GRAPH", "") in ("kernels", "all")   # experiments only
+        GRAPHS_OK = False
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
+    def reduce_max(dt):
+        if dist is None:
+            return dt
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     from pytorchltr_amd import _C
-    from pytorchltr_amd import loss as L_
-    from pytorchltr_amd.fused import FusedLinearLoss
     _C.lib()                                            # fail loudly if the extension is missing
 
-    B, L, F, kind = WORKLOADS[args.workload]
-    scores, relevance, n, X = synth(B, L, F, 1000 * rank, dev)
-    if args.full_lists:
-        n = torch.full_like(n, L)
-    fused = FusedLinearLoss(F, kind).to(dev)
-    lib = _C.lib()
-    kind_id = getattr(_C, kind.upper())
-    W = fused.weight.detach().reshape(F).contiguous()
-    bvec = fused.bias.detach().reshape(1).contiguous()
-    lossv = torch.empty(B, device=dev)
-    ws_bytes = lib.ltr_linear_workspace_bytes(B, L, F)
-    part = torch.empty(ws_bytes // 4, device=dev)
-    # [dW (F) | db (1) | loss_sum | count]: the one bucket that is all-reduced when N > 1
-    flat = torch.zeros(F + 3, device=dev)
-    flat[F + 2] = float(B)
-    # uniform upstream gradient 1/(B*N): after the SUM all-reduce the bucket holds the gradient
-    # of the GLOBAL mean loss -- what `.mean().backward()` gives on the unsharded batch
-    go = torch.full((B,), 1.0 / (B * n_gpus), device=dev)
-
-    def cur_stream():
-        # resolved per call: inside hipGraph capture the current stream is the capture stream
-        return torch.cuda.current_stream().cuda_stream
-
-    # ---- the step: fused scorer + loss forward, backward to dW/db, through the C ABI ----
-    def fwd_bwd():
-        st = cur_stream()
-        _C.check(lib.ltr_linear_partials_f32(
-            kind_id, 1.0, X.data_ptr(), W.data_ptr(), bvec.data_ptr(), relevance.data_ptr(),
-            _C.LABEL_I64, n.data_ptr(), B, L, F, lossv.data_ptr(), None, part.data_ptr(), st))
-        _C.check(lib.ltr_linear_reduce_loss_f32(part.data_ptr(), go.data_ptr(), lossv.data_ptr(), B, F,
-                                                flat.data_ptr(), flat.data_ptr() + 4 * F,
-                                                flat.data_ptr() + 4 * (F + 1), st))
-
-    def fwd_bwd_allreduce():
-        fwd_bwd()
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-
-    results = {}
-    modes = {}
-    if dist is None:
-        modes["eager"] = fwd_bwd
-        replay = None if args.no_graph else try_graph(fwd_bwd)
-        if replay is not None:
-            modes["hipgraph"] = replay
+    Bg, L, F, kind = WORKLOADS[args.workload]
+    if args.shard:
+        if Bg % n_gpus != 0:
+            raise SystemExit("--shard: global batch %d is not divisible by %d ranks" % (Bg, n_gpus))
+        B = Bg // n_gpus
     else:
-        modes["eager"] = fwd_bwd_allreduce
-        dist_graph = os.environ.get("LTR_BENCH_DIST_GRAPH", "")
-        if dist_graph == "kernels":                 # graph of the two kernels + eager collective
-            replay = try_graph(fwd_bwd)
-            if replay is not None:
-                def graph_then_allreduce():
-                    replay()
-                    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-                modes["hipgraph_kernels+eager_allreduce"] = graph_then_allreduce
-        elif dist_graph == "all":                   # the collective captured too
-            replay = try_graph(fwd_bwd_allreduce)
-            if replay is not None:
-                modes["hipgraph_with_allreduce"] = replay
-    for name, fn in modes.items():
-        for _ in range(args.warmup):
-            fn()
-        elapsed = time_wall(fn, args.steps, barrier)
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        if dist is not None:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        results[name] = float(t.item())
-    mode = min(results, key=results.get)
-    elapsed = results[mode]
-    value = n_gpus * B * args.steps / elapsed
+        B = Bg
+    nbuf = nbuf_for(B, L, F)
+    batches = make_batches(B, L, F, nbuf, 1000 * rank, dev, full=args.full_lists)
+    fs = FusedStep(kind, B, L, F, dev, n_gpus=n_gpus)
+    accum = max(1, args.accum) if dist is not None else 1
+
+    # ---- the timed step: fused scorer + loss forward, backward to dW/db, eager, through the C ABI ----
+    if dist is None:
+        def step(i):
+            fs.step(batches[i % nbuf])
+    else:
+        def step(i):
+            j = i % accum
+            fs.step(batches[i % nbuf], accumulate=(j != 0))
+            if j == accum - 1:
+                dist.all_reduce(fs.flat, op=dist.ReduceOp.SUM)
+
+    for i in range(max(args.warmup, 2 * nbuf)):
+        step(i)
+    torch.cuda.synchronize()
+    # enough steps for a >= 50 ms timed region, a multiple of the all-reduce period
+    t0 = time.perf_counter()
+    for i in range(20 * accum):
+        step(i)
+    torch.cuda.synchronize()
+    est = (time.perf_counter() - t0) / (20 * accum)
+    steps_timed = max(args.steps, int(math.ceil(0.05 / max(est, 1e-7))))
+    if dist is not None:
+        t = torch.tensor([steps_timed], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        steps_timed = int(t.item())
+    steps_timed = ((steps_timed + accum - 1) // accum) * accum
+    regions = time_region(step, steps_timed, barrier, repeats=5, reduce_max=reduce_max)
+    elapsed = median(regions)
+    value = n_gpus * B * steps_timed / elapsed
 
     out = None
     if rank == 0:
-        # ---- roofline of the dominant kernel: fused scorer+loss, timed live with HIP events ----
-        def launch_fused():
-            _C.check(lib.ltr_linear_partials_f32(
-                kind_id, 1.0, X.data_ptr(), W.data_ptr(), bvec.data_ptr(),
-                relevance.data_ptr(), _C.LABEL_I64, n.data_ptr(), B, L, F, lossv.data_ptr(), None,
-                part.data_ptr(), cur_stream()))
+        extra = {"timed_regions_s": regions, "steps_per_region": steps_timed}
+        # ---- roofline of the dominant kernel: fused scorer+loss, cold, timed live with HIP events ----
+        k_us, graphed = time_launches(lambda i: fs.kernel(batches[i % nbuf]), nbuf)
+        k_evt = time_events(lambda i: fs.kernel(batches[i % nbuf]), 100)
+        moved = moved_bytes(batches, B, L, F)
+        padded = padded_bytes(B, L, F)
+        pmc = pmc_record(args.workload).get(fs.plan, {}) if not args.full_lists else {}
+        roofline = {
+            "bound": "hbm", "achieved": moved / (k_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": moved / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "traffic": pmc.get("hbm_bytes_per_launch"),
+            "basis": "bytes the launch must move: the n[b] real rows of each query (features + int64 "
+                     "labels), n, W, loss and the (F+1) partials per query; %d batches in rotation "
+                     "(%.0f MB of features > 256 MiB Infinity Cache), so every launch streams from HBM"
+                     % (nbuf, nbuf * 4 * B * L * F / 1e6),
+            "kernel": "%s<%s> (via ltr_linear_partials_f32)" % (fs.plan, kind),
+            "kernel_us_avg": k_us,
+            "timing": "HIP events around %s back-to-back launches over %d rotating batches" % (
+                "hipGraph-replayed" if graphed else "eager", nbuf),
+            "kernel_us_single_launch_event_pair": {"avg": k_evt[0], "median": k_evt[1], "min": k_evt[2]},
+            "moved_bytes_per_launch": moved,
+            "padded_formula": {"bytes_per_launch": padded, "achieved": padded / (k_us * 1e-6) / 1e9,
+                               "frac": padded / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                               "note": "SURVEY.md 8(d) bytes (padded rows counted although never read)"},
+            "valu_issue_frac": valu_frac(pmc.get("valu_insts_per_launch"), k_us),
+        }
+        if n_gpus == 1 and not args.full_lists and not args.no_extra:
+            full_res, _, _ = measure_config(args.workload, B, L, F, kind, dev, 2000, full=True)
+            roofline["full_lists"] = {k: full_res[k] for k in (
+                "workload", "kernel_us", "step_us", "moved_bytes_per_launch", "moved_GBs", "frac_moved",
+                "batches_in_rotation", "timing")}
+            roofline["full_lists"]["frac"] = full_res["frac_moved"]
 
-        for _ in range(10):
-            launch_fused()
-        k_evt_avg, k_evt_med, k_evt_min = time_events(launch_fused, 100)
-        k_avg, k_graphed = time_launches(launch_fused)
-        # algorithmic bytes per query of the fused step: features 4LF read
-        # once + labels 8L + n 8 + W/bias 4(F+1) amortised per launch + loss 4 + partials 4(F+1)
-        alg_bytes = B * (4 * L * F + 8 * L + 8 + 4 + 4 * (F + 1)) + 4 * (F + 1)
-        achieved = alg_bytes / (k_avg * 1e-6) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-        if os.path.exists(tpath):
-            with open(tpath) as fh:
-                traffic = json.load(fh).get("hbm_bytes_per_launch")
-        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "kernel": "%s<%s> (via ltr_linear_partials_f32)" % (fused_kernel_name(kind_id, B, L, F), kind),
-                    "kernel_us_avg": k_avg,
-                    "timing": "HIP events around %s back-to-back launches" % ("hipGraph-replayed" if k_graphed else "eager"),
-                    "kernel_us_single_launch_event_pair": {"avg": k_evt_avg, "median": k_evt_med, "min": k_evt_min},
-                    "algorithmic_bytes_per_launch": alg_bytes}
-
-        # ---- loss-only drop-in path (the literal "loss fwd+bwd" of the metric) ----
-        loss_cls = {"hinge": L_.PairwiseHingeLoss, "dcg_hinge": L_.PairwiseDCGHingeLoss,
-                    "logistic": L_.PairwiseLogisticLoss, "arp1": L_.LambdaARPLoss1,
-                    "arp2": L_.LambdaARPLoss2, "ndcg1": L_.LambdaNDCGLoss1,
-                    "ndcg2": L_.LambdaNDCGLoss2}[kind]
-        loss_fn = loss_cls()
-        sc = scores.clone().requires_grad_(True)
-
-        def loss_step():
-            sc.grad = None
-            loss_fn(sc, relevance, n).mean().backward()
-
-        extra = {"step_seconds": results}
-
-        def measure(stepfn):
-            for _ in range(args.warmup):
-                stepfn()
-            res = {"eager_queries_per_s": B * args.steps / time_wall(stepfn, args.steps, lambda: None)}
-            rp = None if args.no_graph else try_graph(stepfn)
+        if not args.no_graph and dist is None:
+            rp = try_graph(lambda: [fs.step(batches[i]) for i in range(nbuf)])
             if rp is not None:
-                res["hipgraph_queries_per_s"] = B * args.steps / time_wall(rp, args.steps, lambda: None)
-            return res
-
-        # (a) the fused op as an autograd module: FusedLinearLoss(...)(xs, ys, n).mean().backward()
-        params = [fused.weight, fused.bias]
-
-        def module_step():
-            for p_ in params:
-                p_.grad = None
-            fused(X, relevance, n).mean().backward()
-        extra["fused_module_autograd"] = measure(module_step)
-
-        # (b) the reference's own user code, unfused drop-in: torch Linear + our loss module
-        lin = torch.nn.Linear(F, 1).to(dev)
-
-        def dropin_step():
-            lin.weight.grad = None
-            lin.bias.grad = None
-            loss_fn(lin(X), relevance, n).mean().backward()
-        extra["dropin_linear_plus_loss_module"] = measure(dropin_step)
-
-        # (b2) the same user code with the package's streaming scorer in place of nn.Linear
-        from pytorchltr_amd.fused import LinearScorer
-        scorer = LinearScorer(F).to(dev)
-
-        def dropin_scorer_step():
-            scorer.weight.grad = None
-            scorer.bias.grad = None
-            loss_fn(scorer(X, n), relevance, n).mean().backward()
-        extra["dropin_linearscorer_plus_loss_module"] = measure(dropin_scorer_step)
-
-        # (c) loss only (the literal "loss fwd+bwd" on precomputed scores)
-        extra["loss_only_module"] = measure(loss_step)
-        dsc = torch.empty(B, L, device=dev)
-
-        def launch_loss():
-            _C.check(lib.ltr_pairwise_loss_f32(
-                getattr(_C, kind.upper()), 1.0, scores.data_ptr(), relevance.data_ptr(),
-                _C.LABEL_I64, n.data_ptr(), B, L, lossv.data_ptr(), dsc.data_ptr(), cur_stream()))
-
-        for _ in range(10):
-            launch_loss()
-        l_evt_avg, l_evt_med, l_evt_min = time_events(launch_loss, 100)
-        l_avg, _ = time_launches(launch_loss)
-        loss_bytes = B * (16 * L + 16)
-        extra["loss_kernel"] = {"kernel": "pairwise_loss_kernel<%s>" % kind, "us_avg": l_avg,
-                                "us_single_launch_event_pair": {"avg": l_evt_avg, "median": l_evt_med, "min": l_evt_min},
-                                "algorithmic_bytes_per_launch": loss_bytes,
-                                "achieved_GBs": loss_bytes / (l_avg * 1e-6) / 1e9,
-                                "frac_of_hbm_peak": loss_bytes / (l_avg * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                rg = time_region(lambda i: rp(), max(1, steps_timed // nbuf), lambda: None, repeats=3)
+                extra["hipgraph_replay_queries_per_s"] = B * nbuf * max(1, steps_timed // nbuf) / median(rg)
 
         if n_gpus == 1:
-            mlp = mlp_extra(kind, X, relevance, n, args.no_graph)
-            if mlp is not None:
-                extra["mlp_scorer_fused"] = mlp
-
+            extra["loss_kernel"] = loss_kernel_extra(args.workload, kind, B, L, dev, batches)
+        if n_gpus == 1 and not args.no_extra:
+            extra.update(n1_extras(args, kind, B, L, F, dev, batches, steps_timed))
         cpu = None
         if n_gpus == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(kind, B, L, F)
 
         out = {
-            "metric": "queries/sec loss fwd+bwd (B=%d, list_len=%d) + achieved HBM GB/s" % (B, L),
+            "metric": "queries/sec loss fwd+bwd (B=%d, list_len=%d) + achieved HBM GB/s" % (Bg, L),
             "value": value, "unit": "queries/s", "n_gpus": n_gpus, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
+            "warmup": args.warmup, "ms_per_step": elapsed / steps_timed * 1e3,
+            "higher_is_better": True, "scaling": "strong" if args.shard else "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: Linear(%d,1) scorer + %s loss fwd+bwd, B=%d/GPU, "
                                    "list_len=%d, n~U[1,%d]%s" % (args.workload, F, kind, B, L, L,
                                                                 " (full lists)" if args.full_lists else ""),
                        "global_batch": n_gpus * B, "list_len": L, "features": F, "loss": kind,
-                       "mode": mode, "parallelism": "dp%d" % n_gpus},
+                       "mode": "eager", "parallelism": "dp%d" % n_gpus,
+                       "batches_in_rotation": nbuf, "steps_timed": steps_timed, "repeats": 5,
+                       "statistic": "median of 5 timed regions",
+                       "allreduce_every": accum if dist is not None else None},
             "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
         }
     barrier()
@@ -495,6 +623,160 @@ def main():
     if out is not None:
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     os.close(result_fd)
+
+
+def loss_kernel_extra(workload, kind, B, L, dev, batches):
+    """The loss kernel alone (the literal "loss fwd+bwd" on precomputed scores): VALU-issue bound
+    (DESIGN.md section 4), so both an HBM and a VALU-issue fraction are reported."""
+    from pytorchltr_amd import _C
+    lib = _C.lib()
+    nbuf = len(batches)
+    dsc = torch.empty(B, L, device=dev)
+    lossv = torch.empty(B, device=dev)
+    kid = getattr(_C, kind.upper())
+
+    def launch_loss(i):
+        b = batches[i % nbuf]
+        _C.check(lib.ltr_pairwise_loss_f32(kid, 1.0, b["scores"].data_ptr(), b["rel"].data_ptr(), _C.LABEL_I64,
+                                           b["n"].data_ptr(), B, L, lossv.data_ptr(), dsc.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream))
+    for i in range(10):
+        launch_loss(i)
+    l_us, _ = time_launches(launch_loss, nbuf)
+    loss_bytes = B * (16 * L + 16)
+    pmc = pmc_record(workload).get("pairwise_loss_kernel", {})
+    return {"kernel": "pairwise_loss_kernel<%s>" % kind, "us_avg": l_us, "bound": "valu",
+            "algorithmic_bytes_per_launch": loss_bytes,
+            "achieved_GBs": loss_bytes / (l_us * 1e-6) / 1e9,
+            "frac_of_hbm_peak": loss_bytes / (l_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "valu_issue_frac": valu_frac(pmc.get("valu_insts_per_launch"), l_us),
+            "valu_basis": "SQ_INSTS_VALU per launch (profiles/pmc_%s.json) / (256 wave-instructions per "
+                          "cycle x 2.4 GHz x duration)" % workload}
+
+
+def n1_extras(args, kind, B, L, F, dev, batches, steps_timed):
+    """Everything else the N=1 line carries: the reference-signature (drop-in) paths, the loss-only
+    kernel, the other BASELINE configs, the MLP scorer, the forced-dist all-reduce probe."""
+    from pytorchltr_amd import _C
+    from pytorchltr_amd import loss as L_
+    from pytorchltr_amd.evaluation import ndcg
+    from pytorchltr_amd.fused import FusedLinearLoss, LinearScorer
+    lib = _C.lib()
+    extra = {}
+    nbuf = len(batches)
+    b0 = batches[0]
+    loss_cls = {"hinge": L_.PairwiseHingeLoss, "dcg_hinge": L_.PairwiseDCGHingeLoss,
+                "logistic": L_.PairwiseLogisticLoss, "arp1": L_.LambdaARPLoss1,
+                "arp2": L_.LambdaARPLoss2, "ndcg1": L_.LambdaNDCGLoss1,
+                "ndcg2": L_.LambdaNDCGLoss2}[kind]
+    loss_fn = loss_cls()
+    reps = max(200, min(steps_timed, 2000))
+
+    def measure(stepfn):
+        for _ in range(20):
+            stepfn()
+        res = {"eager_queries_per_s": B * reps / median(time_region(lambda i: stepfn(), reps, lambda: None, repeats=3))}
+        res["eager_us_per_step"] = B / res["eager_queries_per_s"] * 1e6
+        rp = None if args.no_graph else try_graph(stepfn)
+        if rp is not None:
+            res["hipgraph_queries_per_s"] = B * reps / median(time_region(lambda i: rp(), reps, lambda: None, repeats=3))
+        return res
+
+    # (a) the fused op as an autograd module: FusedLinearLoss(...)(xs, ys, n).mean().backward()
+    fused = FusedLinearLoss(F, kind).to(dev)
+    params = [fused.weight, fused.bias]
+
+    def module_step():
+        for p_ in params:
+            p_.grad = None
+        fused(b0["X"], b0["rel"], b0["n"]).mean().backward()
+    extra["fused_module_autograd"] = measure(module_step)
+
+    # (b) the reference's own user code, unfused drop-in: torch Linear + our loss module
+    lin = torch.nn.Linear(F, 1).to(dev)
+
+    def dropin_step():
+        lin.weight.grad = None
+        lin.bias.grad = None
+        loss_fn(lin(b0["X"]), b0["rel"], b0["n"]).mean().backward()
+    extra["dropin_linear_plus_loss_module"] = measure(dropin_step)
+
+    # (b2) the same user code with the package's streaming scorer in place of nn.Linear
+    scorer = LinearScorer(F).to(dev)
+
+    def dropin_scorer_step():
+        scorer.weight.grad = None
+        scorer.bias.grad = None
+        loss_fn(scorer(b0["X"], b0["n"]), b0["rel"], b0["n"]).mean().backward()
+    extra["dropin_linearscorer_plus_loss_module"] = measure(dropin_scorer_step)
+
+    # (c) loss only (the literal "loss fwd+bwd" on precomputed scores), reference call signature
+    sc = b0["scores"].clone().requires_grad_(True)
+
+    def loss_step():
+        sc.grad = None
+        loss_fn(sc, b0["rel"], b0["n"]).mean().backward()
+    extra["loss_only_module"] = measure(loss_step)
+
+    # ---- the other BASELINE configs, cold, same method (configs[2..4]; per-GPU shards of C4 / C5) ----
+    cfgs = {}
+    todo = [("c3", WORKLOADS["c3"], None), ("c4", WORKLOADS["c4"], None), ("c4_shard8", (32, 1000, 220, "dcg_hinge"), "c4"),
+            ("c5", WORKLOADS["c5"], None), ("c5_shard8", (64, 512, 700, "hinge"), "c5")]
+    for name, (b_, l_, f_, k_), base in todo:
+        if name == args.workload:
+            continue
+        try:
+            res, fs_, bt_ = measure_config(base or name, b_, l_, f_, k_, dev, 3000,
+                                           label="%s: Linear(%d,1) + %s, B=%d, list_len=%d, n~U[1,%d]%s" % (
+                                               name, f_, k_, b_, l_, l_,
+                                               " (the per-GPU shard of %s at 8 GPUs)" % base if base else ""))
+            if base:
+                res["traffic"] = None
+                res["valu_issue_frac"] = None
+            if name == "c3":
+                # the evaluation half of configs[2]: ndcg@10 on the same batch
+                sc3 = bt_[0]["scores"]
+                mout = torch.empty(b_, device=dev)
+
+                def launch_ndcg(i):
+                    bb = bt_[i % len(bt_)]
+                    _C.check(lib.ltr_dcg_f32(bb["scores"].data_ptr(), bb["rel"].data_ptr(), _C.LABEL_I64,
+                                             bb["n"].data_ptr(), b_, l_, 10, 1, 1, mout.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream))
+                for i in range(5):
+                    launch_ndcg(i)
+                m_us, _ = time_launches(launch_ndcg, len(bt_))
+                res["ndcg_at_10_kernel_us"] = m_us
+                with torch.no_grad():
+                    for _ in range(20):
+                        ndcg(sc3, bt_[0]["rel"], bt_[0]["n"], k=10)
+                    res["ndcg_at_10_eager_call_us"] = median(time_region(
+                        lambda i: ndcg(sc3, bt_[0]["rel"], bt_[0]["n"], k=10), 200, lambda: None, repeats=3)) / 200 * 1e6
+            cfgs[name] = res
+            del fs_, bt_
+            torch.cuda.empty_cache()
+        except Exception as exc:  # pragma: no cover
+            cfgs[name] = {"error": repr(exc)}
+    extra["configs"] = cfgs
+
+    mlp = mlp_extra(kind, batches, args.no_graph)
+    if mlp is not None:
+        extra["mlp_scorer_fused"] = mlp
+
+    # ---- multi-GPU is unmeasured here (1-GPU box): cost of the per-step collective at one rank ----
+    try:
+        env = dict(os.environ)
+        env.pop("LTR_BENCH_FORCE_DIST", None)
+        env["MASTER_PORT"] = str(29700 + os.getpid() % 200)
+        pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--allreduce-probe"], env=env,
+                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120)
+        line = [ln for ln in pr.stdout.decode().splitlines() if ln.startswith("{")]
+        extra["allreduce_probe_1rank"] = json.loads(line[-1]) if line else {"error": "no output, rc=%d" % pr.returncode}
+        extra["allreduce_probe_1rank"]["note"] = ("RCCL process group with ONE rank on this box; scaling over xGMI is "
+                                                  "unmeasured by the builder (no multi-GPU box)")
+    except Exception as exc:  # pragma: no cover
+        extra["allreduce_probe_1rank"] = {"error": repr(exc)}
+    return extra
 
 
 if __name__ == "__main__":

@@ -16,6 +16,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
+import _benchutil as _bu  # noqa: E402
 
 F32_MFMA_PEAK_TF = 157.3
 
@@ -62,7 +63,7 @@ def main():
     for _ in range(5):
         launch()
     torch.cuda.synchronize()
-    us, graphed = bench.time_launches(launch, per_graph=10, replays=10)
+    us, graphed = _bu.time_launches(launch, per_graph=10, replays=10)
     docs = int(n.clamp(max=L).sum())
     flops_per_doc = 2 * (F * H1 + H1 * H2 + H2) + 2 * (F * H1 + 2 * H1 * H2 + H2)   # fwd + bwd (no dX)
     out = {
@@ -82,7 +83,7 @@ def main():
                                         B, L, F, H1, H2, sc.data_ptr(), torch.cuda.current_stream().cuda_stream))
     for _ in range(5):
         launch_scores()
-    us_s, _ = bench.time_launches(launch_scores, per_graph=10, replays=10)
+    us_s, _ = _bu.time_launches(launch_scores, per_graph=10, replays=10)
     out["scores_only_us"] = us_s
 
     def torch_scores():
@@ -92,7 +93,7 @@ def main():
             return torch.nn.functional.linear(h, m.l3.weight, m.l3.bias)
     for _ in range(5):
         torch_scores()
-    us_t, _ = bench.time_launches(torch_scores, per_graph=5, replays=10)
+    us_t, _ = _bu.time_launches(torch_scores, per_graph=5, replays=10)
     out["scores_only_torch_layers_us"] = us_t
     if not args.no_unfused:
         loss_fn = {"hinge": L_.PairwiseHingeLoss, "dcg_hinge": L_.PairwiseDCGHingeLoss,
@@ -113,10 +114,10 @@ def main():
         for name, fn in (("unfused_torch_layers_plus_loss", unfused), ("fused_module_autograd", module)):
             for _ in range(5):
                 fn()
-            res = {"eager_us": bench.time_wall(fn, 50, lambda: None) / 50 * 1e6}
+            res = {"eager_us": _bu.time_wall(fn, 50, lambda: None) / 50 * 1e6}
             rp = bench.try_graph(fn)
             if rp is not None:
-                res["hipgraph_us"] = bench.time_wall(rp, 100, lambda: None) / 100 * 1e6
+                res["hipgraph_us"] = _bu.time_wall(rp, 100, lambda: None) / 100 * 1e6
             out[name] = res
     print(json.dumps(out))
 

@@ -10,6 +10,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
+import _benchutil as _bu  # noqa: E402
 from pytorchltr_amd import _C  # noqa: E402
 from pytorchltr_amd.fused import FusedLinearLoss, LinearScorer  # noqa: E402
 from pytorchltr_amd.loss import PairwiseHingeLoss  # noqa: E402
@@ -31,7 +32,7 @@ for B, L, F in ((1024, 128, 136), (512, 512, 700), (256, 1000, 220), (32, 1000, 
         for _ in range(5):
             step()
         rp = bench.try_graph(step)
-        t = bench.time_wall(rp or step, 100, lambda: None) / 100 * 1e6
+        t = _bu.time_wall(rp or step, 100, lambda: None) / 100 * 1e6
         res.append("%s + loss: %.1f us" % (name, t))
     fl = FusedLinearLoss(F, "hinge").to(dev)
     pf = list(fl.parameters())
@@ -43,7 +44,7 @@ for B, L, F in ((1024, 128, 136), (512, 512, 700), (256, 1000, 220), (32, 1000, 
     for _ in range(5):
         fstep()
     rp = bench.try_graph(fstep)
-    res.append("FusedLinearLoss: %.1f us" % (bench.time_wall(rp or fstep, 100, lambda: None) / 100 * 1e6))
+    res.append("FusedLinearLoss: %.1f us" % (_bu.time_wall(rp or fstep, 100, lambda: None) / 100 * 1e6))
     W = torch.randn(F, device=dev)
     bias = torch.zeros(1, device=dev)
     sc = torch.empty(B, L, device=dev)
@@ -59,6 +60,6 @@ for B, L, F in ((1024, 128, 136), (512, 512, 700), (256, 1000, 220), (32, 1000, 
     for nm, fn in (("scores", k1), ("grad", k3)):
         for _ in range(5):
             fn()
-        t, _ = bench.time_launches(fn, per_graph=10, replays=10)
+        t, _ = _bu.time_launches(fn, per_graph=10, replays=10)
         res.append("%s kernel %.1f us (%.2f TB/s of real rows)" % (nm, t, real / (t * 1e-6) / 1e12))
     print("B=%d L=%d F=%d | " % (B, L, F) + " | ".join(res), flush=True)

@@ -3,7 +3,7 @@ graph-batched), to calibrate what 36/71 MB cost at best."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import time_events, time_launches
+from _benchutil import time_events, time_launches
 dev = torch.device("cuda:0")
 for mb in (4, 18, 36, 71, 142, 568):
     n = mb * 1024 * 1024 // 4

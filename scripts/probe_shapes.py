@@ -1,7 +1,7 @@
 import sys, torch
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/scripts')
 import tune
-from bench import time_launches
+from _benchutil import time_launches
 from pytorchltr_amd import _C
 dev=torch.device('cuda:0')
 for (B,L,F) in ((1024,200,136),(1024,600,32),(512,300,64),(1024,128,136)):

@@ -5,7 +5,7 @@ when the grid is large enough to be throughput-bound."""
 import os, sys, json, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import time_launches
+from _benchutil import time_launches
 from pytorchltr_amd import _C
 dev = torch.device("cuda:0")
 lib = _C.lib()

@@ -2,7 +2,8 @@
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import WORKLOADS, synth, time_launches
+from bench import WORKLOADS, synth
+from _benchutil import time_launches
 from pytorchltr_amd import _C
 dev = torch.device("cuda:0")
 lib = _C.lib()

@@ -9,7 +9,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import WORKLOADS, synth, time_events, time_launches  # noqa: E402
+from bench import WORKLOADS, synth  # noqa: E402
+from _benchutil import time_events, time_launches  # noqa: E402
 from pytorchltr_amd import _C  # noqa: E402
 
 KIND = {"hinge": 0, "dcg_hinge": 1, "logistic": 2, "arp1": 3, "arp2": 4, "ndcg1": 5, "ndcg2": 6}

@@ -84,3 +84,13 @@ def _native_libraries_present():
         build.build_extension()
     if not os.path.exists(build.IO_LIB_PATH):
         build.build_io()
+
+
+@pytest.fixture(autouse=True)
+def _index_tie_breaking():
+    """The parity tests compare with the oracle's deterministic index tie rule; the reference-like
+    random tie-break (the package default) is exercised explicitly by tests/test_ties.py."""
+    from pytorchltr_amd import _ties
+    prev = _ties.set_tie_breaking("index")
+    yield
+    _ties.set_tie_breaking(prev)

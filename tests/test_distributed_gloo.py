@@ -82,3 +82,63 @@ def test_allreduce_step_is_identity_without_process_group():
     mean_loss, count = allreduce_step(g, torch.tensor(10.0), 2)
     assert torch.equal(g[0], torch.tensor([1.0, 2.0])) and torch.equal(g[1], torch.tensor([3.0]))
     assert float(mean_loss) == 5.0 and float(count) == 2.0
+
+
+def _bucket_worker(rank, world, port, B, L, F, accum, out_dir):
+    """bench.py's N > 1 step on CPU: `accum` micro-batches accumulated into the bucket
+    [dW | db | loss_sum | count] with upstream gradient 1/(B*N), then ONE all-reduce."""
+    import bench
+    from oracle import ltr_oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        flat = torch.zeros(F + 3)
+        dW, db, lsum, cnt = bench.bucket_views(flat, F)
+        cnt[0] = float(B)
+        go = np.full(B, 1.0 / (B * world))
+        for j in range(accum):
+            s, y, n, X, W, b = synth(B, L, 1000 * rank + j, F=F)       # bench: seeds 1000*rank + i
+            W0 = synth(B, L, 0, F=F)[4]                               # replicated scorer weights
+            loss, _, gW, gb = O.linear_pairwise("hinge", X.numpy(), W0.numpy(), 0.25, y.numpy(), n.numpy(), go)
+            upd = (torch.tensor(gW, dtype=torch.float32), torch.tensor([gb], dtype=torch.float32),
+                   torch.tensor([loss.sum()], dtype=torch.float32))
+            for view, val in zip((dW, db, lsum), upd):                # reduce kernel: accumulate = (j != 0)
+                view.copy_(val if j == 0 else view + val)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        np.save(os.path.join(out_dir, "bucket%d.npy" % rank), flat.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_bucket_layout_with_accumulation_two_ranks(tmp_path):
+    """After the SUM all-reduce the bucket holds, per micro-batch, the gradient of the GLOBAL mean
+    loss -- i.e. what `accum` calls of `.mean().backward()` on the unsharded batches accumulate --
+    plus the loss total and the query count of all ranks."""
+    from oracle import ltr_oracle as O
+    B, L, F, accum, world = 6, 10, 4, 3, 2
+    port = _free_port()
+    mp.spawn(_bucket_worker, args=(world, port, B, L, F, accum, str(tmp_path)), nprocs=world, join=True)
+    W0 = synth(B, L, 0, F=F)[4]
+    want_dW = np.zeros(F)
+    want_db = 0.0
+    want_loss = 0.0
+    for j in range(accum):
+        Xs, ys, ns = [], [], []
+        for rank in range(world):
+            s, y, n, X, W, b = synth(B, L, 1000 * rank + j, F=F)
+            Xs.append(X), ys.append(y), ns.append(n)
+        Xg, yg, ng = torch.cat(Xs), torch.cat(ys), torch.cat(ns)
+        loss, _, gW, gb = O.linear_pairwise("hinge", Xg.numpy(), W0.numpy(), 0.25, yg.numpy(), ng.numpy(),
+                                            np.full(world * B, 1.0 / (world * B)))
+        want_dW += gW
+        want_db += gb
+        want_loss += loss.sum()
+    import bench
+    for rank in range(world):
+        flat = torch.tensor(np.load(os.path.join(str(tmp_path), "bucket%d.npy" % rank)))
+        dW, db, lsum, cnt = bench.bucket_views(flat, F)
+        assert np.allclose(dW.numpy(), want_dW, rtol=1e-5, atol=1e-6)
+        assert float(db) == pytest.approx(want_db, rel=1e-5, abs=1e-6)
+        assert float(lsum) == pytest.approx(want_loss, rel=1e-5)
+        assert float(cnt) == world * B

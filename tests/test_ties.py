@@ -1,0 +1,154 @@
+"""Tie-breaking of the ranking kernels: the reference orders equal scores by
+one random permutation per call (tiebreak_argsort, utils/tensor_operations.py:29-45), so that a
+constant / zero-initialised scorer gets an unbiased expected metric.  The kernels take that
+permutation as per-position priorities (ltr_*_tie_f32); given the SAME priorities the oracle
+(oracle.ltr_oracle.tie_priorities) must agree bit for bit on tie-heavy rows, counting path and
+sort path alike."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ltr_oracle as O
+
+
+def _tie_heavy(B, L, seed):
+    g = torch.Generator().manual_seed(seed)
+    s = torch.randint(0, 4, (B, L), generator=g).float()          # four distinct scores: many ties
+    y = torch.randint(0, 5, (B, L), generator=g)
+    n = torch.randint(1, L + 1, (B,), generator=g)
+    n[0] = L
+    tie = torch.randperm(L, generator=g).int()
+    return s, y, n, tie
+
+
+def test_oracle_tie_priorities_are_a_permutation_rule():
+    s = np.array([[1.0, 1.0, 1.0, 0.5, 1.0]])
+    n = np.array([4])
+    assert O.rank_by_score(s, n).tolist() == [[0, 1, 2, 3, 4]]
+    with O.tie_priorities([3, 0, 2, 1, 4]):
+        assert O.rank_by_score(s, n).tolist() == [[1, 2, 0, 3, 4]]   # by priority among the real 1.0s
+    assert O.rank_by_score(s, n).tolist() == [[0, 1, 2, 3, 4]]       # context restored
+
+
+def test_mode_switch_and_draw():
+    from pytorchltr_amd import _ties
+    from pytorchltr_amd.utils import get_tie_breaking, set_tie_breaking, tie_breaking
+    prev = set_tie_breaking("random")
+    try:
+        assert get_tie_breaking() == "random"
+        with tie_breaking("index"):
+            assert get_tie_breaking() == "index"
+            assert _ties.draw_priorities(8, torch.device("cpu")) is None
+        assert get_tie_breaking() == "random"
+        p = _ties.draw_priorities(8, torch.device("cpu"))
+        assert p.dtype == torch.int32 and sorted(p.tolist()) == list(range(8))
+        g1 = torch.Generator().manual_seed(3)
+        g2 = torch.Generator().manual_seed(3)
+        with tie_breaking("index"):                                    # an explicit generator always counts
+            a = _ties.draw_priorities(16, torch.device("cpu"), g1)
+        b = _ties.draw_priorities(16, torch.device("cpu"), g2)
+        assert torch.equal(a, b)
+        with pytest.raises(ValueError):
+            set_tie_breaking("stable")
+    finally:
+        set_tie_breaking(prev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L", [7, 64, 100, 256, 300, 1000, 2500, 4096])
+def test_rank_and_metrics_with_priorities_match_oracle(L):
+    from pytorchltr_amd import _C
+    dev = torch.device("cuda:0")
+    B = 6
+    s, y, n, tie = _tie_heavy(B, L, L)
+    sd, yd, nd, td = s.to(dev), y.to(dev), n.to(dev), tie.to(dev)
+    lib = _C.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    ranking = torch.empty(B, L, dtype=torch.int64, device=dev)
+    _C.check(lib.ltr_rank_by_score_tie_f32(sd.data_ptr(), nd.data_ptr(), td.data_ptr(), B, L,
+                                           ranking.data_ptr(), st))
+    out_ndcg = torch.empty(B, device=dev)
+    _C.check(lib.ltr_dcg_tie_f32(sd.data_ptr(), yd.data_ptr(), _C.LABEL_I64, nd.data_ptr(), td.data_ptr(),
+                                 B, L, 10, 1, 1, out_ndcg.data_ptr(), st))
+    out_arp = torch.empty(B, device=dev)
+    y0 = (y * (torch.arange(L)[None, :] < n[:, None])).to(dev)
+    _C.check(lib.ltr_arp_tie_f32(sd.data_ptr(), y0.data_ptr(), _C.LABEL_I64, nd.data_ptr(), td.data_ptr(),
+                                 B, L, out_arp.data_ptr(), st))
+    with O.tie_priorities(tie.numpy()):
+        want_rank = O.rank_by_score(s.numpy(), n.numpy())
+        want_ndcg = O.ndcg(s.numpy(), y.numpy(), n.numpy(), k=10)
+        want_arp = O.arp(s.numpy(), y0.cpu().numpy(), n.numpy())
+    assert np.array_equal(ranking.cpu().numpy(), want_rank)                      # bit-exact, ties included
+    assert np.allclose(out_ndcg.cpu().numpy(), want_ndcg, rtol=2e-5, atol=1e-6)
+    assert np.allclose(out_arp.cpu().numpy(), want_arp, rtol=2e-5, atol=1e-6)
+    # and without priorities: the index rule of the plain entry points
+    _C.check(lib.ltr_rank_by_score_tie_f32(sd.data_ptr(), nd.data_ptr(), None, B, L, ranking.data_ptr(), st))
+    assert np.array_equal(ranking.cpu().numpy(), O.rank_by_score(s.numpy(), n.numpy()))
+
+
+@pytest.mark.gpu
+def test_constant_scorer_is_not_rewarded_for_label_sorted_storage():
+    """The ADVICE example: labels stored best-first (example3 test split: 4,3,2,1) and a scorer whose
+    outputs all tie.  Index order gives NDCG 1.0; the reference's random tie-break -- the default
+    here -- gives the expectation over permutations."""
+    from pytorchltr_amd.evaluation import arp, ndcg
+    from pytorchltr_amd.utils import rank_by_score, tie_breaking
+    dev = torch.device("cuda:0")
+    L = 12
+    y = torch.arange(L - 1, -1, -1).reshape(1, L).repeat(400, 1).to(dev) % 5
+    y, _ = torch.sort(y, dim=1, descending=True)
+    s = torch.zeros(400, L, device=dev)
+    n = torch.full((400,), L, device=dev)
+    with tie_breaking("index"):
+        assert torch.all(ndcg(s, y, n, k=10) == 1.0)
+        best_arp = float(arp(s, y, n)[0])
+    with tie_breaking("random"):
+        torch.manual_seed(0)
+        vals = torch.stack([ndcg(s, y, n, k=10)[0] for _ in range(200)])
+        arps = torch.stack([arp(s, y, n)[0] for _ in range(200)])
+        r1 = rank_by_score(s, n)
+        r2 = rank_by_score(s, n)
+    assert float(vals.mean()) < 0.9 and float(vals.std()) > 0.01
+    assert float(arps.mean()) > best_arp + 0.5
+    assert not torch.equal(r1, r2)                                     # a fresh permutation per call
+    assert sorted(r1[0].tolist()) == list(range(L))
+    assert torch.equal(r1[0], r1[-1])                                  # ONE permutation for all rows
+
+
+@pytest.mark.gpu
+def test_generator_is_honoured():
+    from pytorchltr_amd.utils import rank_by_score, tiebreak_argsort
+    dev = torch.device("cuda:0")
+    s = torch.zeros(3, 50, device=dev)
+    n = torch.tensor([50, 20, 0], device=dev)
+    a = rank_by_score(s, n, generator=torch.Generator().manual_seed(11))
+    b = rank_by_score(s, n, generator=torch.Generator().manual_seed(11))
+    c = rank_by_score(s, n, generator=torch.Generator().manual_seed(12))
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert a[2].tolist() == list(range(50))                            # n = 0: padded tail in index order
+    assert sorted(a[1, :20].tolist()) == list(range(20)) and a[1, 20:].tolist() == list(range(20, 50))
+    gd = torch.Generator(device=dev).manual_seed(5)
+    d = tiebreak_argsort(s, generator=gd)
+    assert sorted(d[0].tolist()) == list(range(50))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L", [50, 300, 1500])
+def test_nan_scores_still_give_a_permutation(L):
+    """NaN scores must not collide in the rank arrays -- packed keys give NaN a
+    total order on the counting path and the sort path alike."""
+    from pytorchltr_amd.evaluation import dcg
+    from pytorchltr_amd.utils import rank_by_score, tie_breaking
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(L)
+    s = torch.randn(4, L, generator=g)
+    s[:, ::3] = float("nan")
+    y = torch.randint(0, 5, (4, L), generator=g)
+    n = torch.tensor([L, L // 2, 1, 0])
+    with tie_breaking("index"):
+        r = rank_by_score(s.to(dev), n.to(dev)).cpu()
+        curve = dcg(s.to(dev), y.to(dev), n.to(dev)).cpu()
+    for b in range(4):
+        assert sorted(r[b].tolist()) == list(range(L))
+    assert torch.all(torch.isfinite(curve))
+    assert torch.all(curve[:, 1:] >= curve[:, :-1])                    # a cumulative sum of gains >= 0
