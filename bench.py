@@ -535,13 +535,18 @@ def main():
     for i in range(max(args.warmup, 2 * nbuf)):
         step(i)
     torch.cuda.synchronize()
-    # enough steps for a >= 50 ms timed region, a multiple of the all-reduce period
-    t0 = time.perf_counter()
-    for i in range(20 * accum):
-        step(i)
-    torch.cuda.synchronize()
-    est = (time.perf_counter() - t0) / (20 * accum)
-    steps_timed = max(args.steps, int(math.ceil(0.05 / max(est, 1e-7))))
+    # enough steps for a >= 50 ms timed region (aim at 60), a multiple of the all-reduce period
+    est_steps = 25 * accum
+    ests = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(est_steps):
+            step(i)
+        torch.cuda.synchronize()
+        ests.append((time.perf_counter() - t0) / est_steps)
+    est = min(ests)
+    steps_timed = max(args.steps, int(math.ceil(0.06 / max(est, 1e-7))))
     if dist is not None:
         t = torch.tensor([steps_timed], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
