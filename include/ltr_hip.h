@@ -254,15 +254,16 @@ int ltr_linear_pairwise_f32(int kind, float sigma, const float *X, const float *
                             void *workspace, size_t workspace_bytes, void *stream);
 
 /* The same step split at the autograd boundary (forward / backward of a fused
- * Linear+loss module): partials is (F+1, B) row-major -- partials[f, b] = d loss[b] / dW_f for
- * f < F, partials[F, b] = d loss[b] / d bias -- so that the reduction over queries reads
- * contiguously; then dW_f = sum_b grad_out[b] * partials[f, b], db likewise (grad_out NULL = 1/B).
- * The `partials` buffer must be ltr_linear_workspace_bytes(B,L,F) bytes (the (F+1)*B matrix,
- * rounded up, plus a reserved tail). */
+ * Linear+loss module): partials is (B, PF) row-major with PF = (F + 4) & ~3 floats per query --
+ * partials[b, f] = d loss[b] / dW_f for f < F, partials[b, F] = d loss[b] / d bias, zero padding
+ * after -- so that a query's row is one contiguous, 16-byte aligned store; then
+ * dW_f = sum_b grad_out[b] * partials[b, f], db likewise (grad_out NULL = 1/B).
+ * The `partials` buffer must be ltr_linear_workspace_bytes(B,L,F) bytes (the B * PF matrix,
+ * rounded up, plus a reserved tail and, for some shapes, kernel scratch). */
 int ltr_linear_partials_f32(int kind, float sigma, const float *X, const float *W,
                             const float *bias, const void *rel, int rel_dtype,
                             const int64_t *n, int B, int L, int F, float *loss,
-                            float *scores_out, float *partials /* (F+1, B) */, void *stream);
+                            float *scores_out, float *partials /* (B, PF) */, void *stream);
 int ltr_linear_reduce_f32(const float *partials, const float *grad_out, int B, int F, float *dW,
                           float *db, void *stream);
 /* Same reduction, additionally writing loss_sum[0] = sum_b loss[b] (the scalar a training loop

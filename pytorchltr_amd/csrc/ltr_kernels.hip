@@ -164,7 +164,12 @@ __device__ __forceinline__ int sched_query_sampled(const int64_t *__restrict__ n
         const int key = clamp_n(n[min(id, B - 1)], L);
         // (all lists equally long, e.g. full lists: cand stays the whole group and rho the lane)
         const bool flat = __ballot(key != __builtin_amdgcn_readfirstlane(key)) == 0ull;
-        for (int bt = flat ? -1 : 31 - __builtin_clz(L); bt >= 0; --bt) {   // descending n: set bits first
+        // (LTR_SCHED_LOW_BITS low bits of n are ignored: an approximate order balances as well and
+        // every bit is one more dependent ballot round in front of the first load)
+#ifndef LTR_SCHED_LOW_BITS
+#define LTR_SCHED_LOW_BITS 3
+#endif
+        for (int bt = flat ? -1 : 31 - __builtin_clz(L); bt >= LTR_SCHED_LOW_BITS; --bt) {   // descending n: set bits first
             const unsigned long long m = __ballot(((key >> bt) & 1) != 0) & cand;
             const int c = __popcll(m);
             if (rho < c) cand = m;
@@ -778,17 +783,26 @@ __device__ __forceinline__ float wave_rol1(float v)
 
 // part / parts: this workgroup is one of `parts` that share the query's pair units (split-query
 // launch); raw: return the plain pair sum (no loss modifier, gscale untouched).
-template <int KIND>
+// TW > 0: the workgroup has TW waves (compile-time: no dispatch-packet read, shifts instead of
+// divisions) and, when it owns the whole query, only as many of them take pair units as the query
+// has work for (at least LTR_SYM_MIN_STEPS steps per wave, a power of two of waves).  Measured (C2,
+// fused hinge step, us): 1 step per wave 11.3, 4: 11.6, 8: 11.9, 16: 12.3 -- the pass is latency-
+// bound, more waves with fewer steps each win, so the default is 1 (every wave that can get a step).
+// Idle waves still publish a zero gradient slice.
+#ifndef LTR_SYM_MIN_STEPS
+#define LTR_SYM_MIN_STEPS 1
+#endif
+template <int KIND, int TW = 0>
 __device__ __forceinline__ float pairwise_core_sym(const QueryLds &q, int nb, int Lt, float sigma,
                                                    float &gscale, int part = 0, int parts = 1,
                                                    bool raw = false)
 {
     const int tid = threadIdx.x;
-    const int T = blockDim.x;
+    const int T = TW > 0 ? TW * 64 : (int)blockDim.x;
     const int lane = tid & 63;
     const int wl = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w = part * (T >> 6) + wl;                      // wave index among all parts
-    const int W = parts * (T >> 6);
+    int w = part * (T >> 6) + wl;                            // wave index among all parts
+    int W = parts * (T >> 6);
     const int nt = (nb + 63) >> 6;
     const float c1 = sigma * kLog2e;
     constexpr bool kRowWeight = (KIND == LTR_ARP1 || KIND == LTR_NDCG1);
@@ -802,8 +816,23 @@ __device__ __forceinline__ float pairwise_core_sym(const QueryLds &q, int nb, in
     const int hc_last = nb - 64 * (nt - 1);
     const int dlast = (hc_last - 1 < 32) ? (hc_last - 1) : 32;
     const int S = (nt > 0) ? (32 * nt * nt - (32 - dlast)) : 0;
-    int u = (w * S) / W;
-    const int u1 = ((w + 1) * S) / W;
+    int u, u1;
+    if (TW > 0 && parts == 1 && (TW & (TW - 1)) == 0) {
+        // waves that take units: the largest power of two <= S / LTR_SYM_MIN_STEPS, in [1, TW]
+        int sh = 0;
+        while ((2 << sh) <= TW && (2 << sh) * LTR_SYM_MIN_STEPS <= S) ++sh;
+        W = 1 << sh;
+        u = (wl * S) >> sh;
+        u1 = (wl < W) ? ((wl + 1) * S) >> sh : u;
+        if (wl >= W) u = u1 = 0;
+        w = wl;
+    } else if (TW > 0 && parts == 1) {
+        u = (wl * S) / TW;                                   // (division by a constant)
+        u1 = ((wl + 1) * S) / TW;
+    } else {
+        u = (w * S) / W;
+        u1 = ((w + 1) * S) / W;
+    }
     // decode the first unit of this wave into (a, b, j): row a of the job triangle holds its
     // diagonal job (32 steps, dlast in the last row) and 64 steps for every b > a -- walk the rows
     // (<= nt iterations), then the column is a division (a job-by-job walk cost up to nt^2/2
@@ -858,14 +887,17 @@ __device__ __forceinline__ float pairwise_core_sym(const QueryLds &q, int nb, in
             const bool on = half ? (lane < 32) : true;
             float c;                                             // d term / d s_home
             if (KIND == LTR_HINGE || KIND == LTR_DCG_HINGE) {
-                // sgn = -1 when the home document is the higher-labelled one; margin term
-                // u = 1 + sgn*(s_home - s_vis); active iff labels differ (ordered compare: a NaN
-                // sentinel never differs) and u >= 0
-                const float sgn = (yh > yv) ? -1.0f : 1.0f;
-                const float uu = __builtin_fmaf(sgn, sh - sv, 1.0f);
-                const bool act = on & __builtin_islessgreater(yh, yv) & (uu >= 0.0f);
-                lacc += act ? uu : 0.0f;
-                c = act ? sgn : 0.0f;
+                // sgn = -1 when the home document is the higher-labelled one, +1 when the visitor is,
+                // 0 when the labels are equal or one of them is the NaN sentinel (ordered compares);
+                // margin term u = |sgn| + sgn*(s_home - s_vis): 0 for an inert pair; the pair counts
+                // iff u >= 0 (non-strict, as the reference leaves the gradient at the margin) -- one
+                // compare feeding selects, no scalar mask arithmetic in the dependency chain
+                float sgn = (yh < yv) ? 1.0f : 0.0f;
+                sgn = (yh > yv) ? -1.0f : sgn;
+                if (half) sgn = on ? sgn : 0.0f;
+                const float uu = __builtin_fmaf(sgn, sh - sv, __builtin_fabsf(sgn));
+                lacc += __builtin_fmaxf(uu, 0.0f);
+                c = (uu >= 0.0f) ? sgn : 0.0f;
             } else if (!kRowWeight) {
                 const bool gt = yh > yv, lt = yh < yv;
                 float Wp = 1.0f;
@@ -921,8 +953,20 @@ __device__ __forceinline__ float pairwise_core_sym(const QueryLds &q, int nb, in
     if (kRowWeight && part == 0)              // the i == j terms: a_i * log2(1 + e^0) = a_i
         for (int k = tid; k < nb; k += T) lacc += q.sy[k].y;
 
-    float total = block_sum(lacc, q.red);     // its barriers publish gpart when there are >= 2 waves
-    if (T == kWave) __syncthreads();
+    float total;
+    if (TW > 0) {
+        // every wave parks its sum in its own slot (the upper half of `red`: no reuse hazard with the
+        // block sums of prepare_ndcg), ONE barrier publishes the sums and the gradient slices
+        const float ws = wave_sum(lacc);
+        if (lane == 0) q.red[16 + wl] = ws;
+        __syncthreads();
+        total = 0.f;
+#pragma unroll
+        for (int i = 0; i < (TW > 0 ? TW : 1); ++i) total += q.red[16 + i];
+    } else {
+        total = block_sum(lacc, q.red);       // its barriers publish gpart when there are >= 2 waves
+        if (T == kWave) __syncthreads();
+    }
     if (raw) return total;
     gscale = 1.0f;
     if (KIND == LTR_DCG_HINGE) {

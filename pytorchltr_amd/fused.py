@@ -98,7 +98,7 @@ class _LinearLossFunction(torch.autograd.Function):
         bvec = None if bias is None else _flat_f32(bias, 1)
         r, nn = _labels_and_n(relevance, n, B, L, dev)
         loss = torch.empty(B, dtype=torch.float32, device=dev)
-        # (F+1, B) partials, then the kernel's scratch
+        # (B, PF) partials, then the kernel's scratch
         ws = torch.empty(_linear_ws_bytes(B, L, F) // 4, dtype=torch.float32, device=dev)
         scores = torch.empty((B, L), dtype=torch.float32, device=dev) if want_scores else None
         if B > 0:
