@@ -3,8 +3,8 @@
 python scripts/trace_regtile.py build/variants/libltr_trace.so [--full] [--kind hinge] [--nbuf 5]
 
 Stamps (100 MHz wall clock, per workgroup, relative to the first workgroup's entry):
-entry | 0 after scheduling | 1 loads landed + dots + barrier | 2 scores folded | 3 pair pass |
-4 gradients final | 5 partials written."""
+entry | 0 after scheduling | 1 loads landed + dots + barrier | 2 scores folded | 3 rankings (NDCG kinds) |
+4 pair pass | 5 gradients final | 6 partials written."""
 import argparse
 import ctypes
 import os
@@ -56,7 +56,7 @@ def main():
     bias = torch.zeros(1, device=dev)
     loss = torch.empty(B, device=dev)
     part = torch.empty(lib.ltr_linear_workspace_bytes(B, L, F) // 4 + 64, device=dev)
-    tr = torch.zeros(B * 8, dtype=torch.int64, device=dev)
+    tr = torch.zeros(B * 16, dtype=torch.int64, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     rows = []
     for rep in range(3 * args.nbuf):
@@ -66,15 +66,15 @@ def main():
         assert rc == 0, rc
         torch.cuda.synchronize()
         if rep >= args.nbuf:
-            rows.append((tr.cpu().view(B, 8).clone(), n.cpu()))
-    names = ["entry", "sched", "loaded", "scores", "pair", "gfin", "end"]
+            rows.append((tr.cpu().view(B, 16).clone(), n.cpu()))
+    names = ["entry", "sched", "loaded", "scores", "ranks", "pair", "gfin", "end"]
     acc = None
     for t, n in rows:
         t = t.clone()
-        meta = t[:, 7]
+        meta = t[:, 15]
         blk = (meta & 0xffffffff)
         order = torch.argsort(blk)
-        ts = torch.stack([t[:, 6]] + [t[:, i] for i in range(6)], dim=1).double()
+        ts = torch.stack([t[:, 14]] + [t[:, i] for i in range(7)], dim=1).double()
         t0 = ts[:, 0].min()
         ts = (ts - t0) * 10.0                       # ns
         ts = ts[order]
@@ -83,16 +83,16 @@ def main():
         out = []
         for qi in range(4):
             sl = slice(qi * q, (qi + 1) * q)
-            out.append(torch.cat([ts[sl].mean(0), ts[sl, 6:7].max(0).values, nn[sl].mean(0, keepdim=True)]))
+            out.append(torch.cat([ts[sl].mean(0), ts[sl, 7:8].max(0).values, nn[sl].mean(0, keepdim=True)]))
         out = torch.stack(out)
         acc = out if acc is None else acc + out
-        span = ts[:, 6].max()
+        span = ts[:, 7].max()
     acc /= len(rows)
     print("%s %s %s: mean ns since first entry, by quartile of block id (dispatch order); last launch span %.0f ns"
           % (args.workload, kind, "full lists" if args.full else "ragged", span))
     print("quartile  " + "  ".join("%8s" % nm for nm in names) + "   max_end   mean_n")
     for qi in range(4):
-        print("   %d     " % qi + "  ".join("%8.0f" % v for v in acc[qi, :7]) + "  %8.0f  %6.1f" % (acc[qi, 7], acc[qi, 8]))
+        print("   %d     " % qi + "  ".join("%8.0f" % v for v in acc[qi, :8]) + "  %8.0f  %6.1f" % (acc[qi, 8], acc[qi, 9]))
     # phase durations averaged over all workgroups of the last launch
     d = ts[:, 1:] - ts[:, :-1]
     print("phase mean ns: " + "  ".join("%s %.0f" % (nm, v) for nm, v in zip(names[1:], d.mean(0))))
