@@ -718,6 +718,14 @@ def n1_extras(args, kind, B, L, F, dev, batches, steps_timed):
     # (c) loss only (the literal "loss fwd+bwd" on precomputed scores), reference call signature
     sc = b0["scores"].clone().requires_grad_(True)
 
+    # the floor of PyTorch's own eager autograd on this host for a graph of the same depth: a
+    # NATIVE elementwise op in place of the loss (no custom Function at all)
+    def native_step():
+        sc.grad = None
+        (sc * 2.0).sum(1).mean().backward()
+    extra["eager_floor_native_ops"] = dict(measure(native_step),
+                                           what="(scores * 2).sum(1).mean().backward(): torch ops only, same graph depth")
+
     def loss_step():
         sc.grad = None
         loss_fn(sc, b0["rel"], b0["n"]).mean().backward()

@@ -3,11 +3,12 @@
 
     python scripts/rocpd_summary.py gpurun_out/prof_r01/bench_results.db > profiles/r01_kernel_stats.txt
 """
+import json
 import sqlite3
 import sys
 
 
-def main(path):
+def main(path, json_out=None):
     con = sqlite3.connect(path)
     cur = con.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
@@ -28,6 +29,15 @@ def main(path):
             "order by kernel_name, counter_name").fetchall()
     except sqlite3.Error:
         pm = []
+    if json_out:
+        doc = {}
+        for name, calls, tot, avg, mn, mx in rows:
+            doc.setdefault(name, {})["calls"] = calls
+            doc[name]["avg_us"] = avg / 1e3
+        for name, ctr, cnt, avg, mn, mx in pm:
+            doc.setdefault(name, {}).setdefault("counters", {})[ctr] = avg
+        with open(json_out, "w") as fh:
+            json.dump(doc, fh, indent=1)
     if pm:
         print("\n# PMC counters per dispatch (avg / min / max over dispatches)")
         for name, ctr, cnt, avg, mn, mx in pm:
@@ -37,4 +47,4 @@ def main(path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
