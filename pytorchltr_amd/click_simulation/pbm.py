@@ -25,6 +25,12 @@ def _simulate_pbm_from_uniform(rankings, ys, n, relevance_probs, uniform, cutoff
     yy = ys.reshape(B, L).to(_torch.int64).contiguous()
     nn = _prepare_n(n, B)
     probs = relevance_probs.to(device=rk.device, dtype=_torch.float32).contiguous()
+    if B > 0 and L > 0:
+        # the reference's gathers raise on bad indices; one combined device-side check here
+        bad = ((yy < 0) | (yy >= probs.numel())).any() | ((rk < 0) | (rk >= L)).any()
+        if bool(bad):
+            raise IndexError("simulate_pbm: labels must index relevance_probs (%d entries) and rankings "
+                             "the %d list positions" % (probs.numel(), L))
     uu = uniform.to(device=rk.device, dtype=_torch.float32).contiguous()
     clicks = _torch.empty(B, L, dtype=_torch.int64, device=rk.device)
     props = _torch.empty(B, L, dtype=_torch.float32, device=rk.device)

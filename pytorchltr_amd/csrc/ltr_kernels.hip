@@ -38,6 +38,11 @@ constexpr float kLn2 = 0.6931471805599453f;
 // call; ltr_device_status() reads / clears it explicitly.  Allocated lazily outside stream capture;
 // until then (or when the allocation fails) the kernels only poison their outputs with NaN.
 // ---------------------------------------------------------------------------------
+// Every launcher reports its launch with hipGetLastError(), which returns (and clears) the LAST error
+// of the calling thread -- including one an unrelated earlier call left behind.  The entry points
+// therefore drop stale state first, so that a non-zero return is about THIS call.
+#define LTR_CLEAR_STALE_ERROR() ((void)hipGetLastError())
+
 struct StatusPage { int *host; int *dev; };
 inline StatusPage &status_page_ref() { static StatusPage sp = {nullptr, nullptr}; return sp; }
 inline int *status_device_ptr(hipStream_t stream)
@@ -1951,6 +1956,7 @@ int ltr_max_list_len(void) { return kMaxListLen; }
 
 int ltr_device_status(int clear)
 {
+    LTR_CLEAR_STALE_ERROR();
     StatusPage &sp = status_page_ref();
     if (!sp.host) return LTR_OK;
     volatile int *w = reinterpret_cast<volatile int *>(sp.host);
@@ -1980,6 +1986,7 @@ int ltr_pairwise_loss_f32_cfg(int kind, float sigma, const float *scores, const 
                               int rel_dtype, const int64_t *n, int B, int L, float *loss,
                               float *dscores, int owners, int dpt, int msplit, void *stream)
 {
+    LTR_CLEAR_STALE_ERROR();
     if (kind < LTR_HINGE || kind > LTR_NDCG2 || bad_label_dtype(rel_dtype)) return LTR_ERR_KIND;
     if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
     if (L > kMaxListLen) return LTR_ERR_LIST_TOO_LONG;
@@ -2004,6 +2011,7 @@ int ltr_pairwise_loss_f32(int kind, float sigma, const float *scores, const void
                           int rel_dtype, const int64_t *n, int B, int L, float *loss,
                           float *dscores, void *stream)
 {
+    LTR_CLEAR_STALE_ERROR();
     if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
     LaunchShape s = choose_loss_shape(B, L);
     while (s.dpt != 0 && s.msplit > 1 && loss_lds_bytes(kind, L, s.msplit) > kLdsBudget) s.msplit /= 2;
@@ -2026,6 +2034,7 @@ int ltr_pairwise_loss_ws_f32(int kind, float sigma, const float *scores, const v
                              int rel_dtype, const int64_t *n, int B, int L, float *loss,
                              float *dscores, void *workspace, size_t workspace_bytes, void *stream)
 {
+    LTR_CLEAR_STALE_ERROR();
     if (kind < LTR_HINGE || kind > LTR_NDCG2 || bad_label_dtype(rel_dtype)) return LTR_ERR_KIND;
     if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
     if (L > kMaxListLen) return LTR_ERR_LIST_TOO_LONG;
@@ -2060,6 +2069,7 @@ int ltr_pairwise_loss_ws_f32(int kind, float sigma, const float *scores, const v
 int ltr_scale_rows_f32(const float *dscores, const float *grad_out, int B, int L, float *out,
                        void *stream)
 {
+    LTR_CLEAR_STALE_ERROR();
     if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
     if (B == 0) return LTR_OK;
     if (!dscores || !grad_out || !out) return LTR_ERR_NULL;
@@ -2078,6 +2088,7 @@ int ltr_scale_rows_f32(const float *dscores, const float *grad_out, int B, int L
 int ltr_scale_rows_uniform_f32(const float *dscores, const float *grad_scalar, int B, int L,
                                float *out, void *stream)
 {
+    LTR_CLEAR_STALE_ERROR();
     if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
     if (B == 0) return LTR_OK;
     if (!dscores || !grad_scalar || !out) return LTR_ERR_NULL;
@@ -2096,6 +2107,7 @@ int ltr_scale_rows_uniform_f32(const float *dscores, const float *grad_scalar, i
 int ltr_rank_by_score_tie_f32(const float *scores, const int64_t *n, const int32_t *tie, int B, int L,
                               int64_t *ranking, void *stream)
 {
+    LTR_CLEAR_STALE_ERROR();
     if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
     if (L > kMaxListLen) return LTR_ERR_LIST_TOO_LONG;
     if (B == 0) return LTR_OK;
@@ -2108,6 +2120,7 @@ int ltr_rank_by_score_tie_f32(const float *scores, const int64_t *n, const int32
 int ltr_rank_by_score_f32(const float *scores, const int64_t *n, int B, int L, int64_t *ranking,
                           void *stream)
 {
+    LTR_CLEAR_STALE_ERROR();
     return ltr_rank_by_score_tie_f32(scores, n, nullptr, B, L, ranking, stream);
 }
 
@@ -2115,6 +2128,7 @@ int ltr_dcg_tie_f32(const float *scores, const void *rel, int rel_dtype, const i
                     const int32_t *tie, int B, int L, int k, int use_exp, int normalize, float *out,
                     void *stream)
 {
+    LTR_CLEAR_STALE_ERROR();
     if (bad_label_dtype(rel_dtype)) return LTR_ERR_KIND;
     if (B < 0 || L <= 0 || k < 0) return LTR_ERR_SHAPE;
     if (L > kMaxListLen) return LTR_ERR_LIST_TOO_LONG;
@@ -2129,12 +2143,14 @@ int ltr_dcg_tie_f32(const float *scores, const void *rel, int rel_dtype, const i
 int ltr_dcg_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n, int B,
                 int L, int k, int use_exp, int normalize, float *out, void *stream)
 {
+    LTR_CLEAR_STALE_ERROR();
     return ltr_dcg_tie_f32(scores, rel, rel_dtype, n, nullptr, B, L, k, use_exp, normalize, out, stream);
 }
 
 int ltr_arp_tie_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n,
                     const int32_t *tie, int B, int L, float *out, void *stream)
 {
+    LTR_CLEAR_STALE_ERROR();
     if (bad_label_dtype(rel_dtype)) return LTR_ERR_KIND;
     if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
     if (L > kMaxListLen) return LTR_ERR_LIST_TOO_LONG;
@@ -2149,12 +2165,14 @@ int ltr_arp_tie_f32(const float *scores, const void *rel, int rel_dtype, const i
 int ltr_arp_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n, int B,
                 int L, float *out, void *stream)
 {
+    LTR_CLEAR_STALE_ERROR();
     return ltr_arp_tie_f32(scores, rel, rel_dtype, n, nullptr, B, L, out, stream);
 }
 
 int ltr_listwise_softmax_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n,
                              int B, int L, float *loss, float *dscores, void *stream)
 {
+    LTR_CLEAR_STALE_ERROR();
     if (bad_label_dtype(rel_dtype)) return LTR_ERR_KIND;
     if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
     if (B == 0) return LTR_OK;
@@ -2176,6 +2194,7 @@ int ltr_listwise_softmax_f32(const float *scores, const void *rel, int rel_dtype
 int ltr_mask_padded_values_f32(const float *xs, const int64_t *n, int B, int L, float mask_value,
                                float *out, void *stream)
 {
+    LTR_CLEAR_STALE_ERROR();
     if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
     if (B == 0) return LTR_OK;
     if (!xs || !n || !out) return LTR_ERR_NULL;
@@ -2187,6 +2206,7 @@ int ltr_mask_padded_values_f32(const float *xs, const int64_t *n, int B, int L, 
 
 int ltr_batch_pairs(const void *x, int elem_bytes, int B, int L, void *out, void *stream)
 {
+    LTR_CLEAR_STALE_ERROR();
     if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
     if (elem_bytes != 4 && elem_bytes != 8) return LTR_ERR_KIND;
     if (B == 0) return LTR_OK;
@@ -2207,6 +2227,7 @@ int ltr_batch_pairs(const void *x, int elem_bytes, int B, int L, void *out, void
 int ltr_plackettluce_keys_f32(const float *scores, const int64_t *n, const float *u, int B, int L,
                               float *keys, void *stream)
 {
+    LTR_CLEAR_STALE_ERROR();
     if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
     if (B == 0) return LTR_OK;
     if (!scores || !n || !u || !keys) return LTR_ERR_NULL;
@@ -2219,6 +2240,7 @@ int ltr_pbm_clicks(const int64_t *rankings, const int64_t *ys, const int64_t *n,
                    const float *relevance_probs, int n_probs, const float *u, int B, int L,
                    int cutoff, float eta, int64_t *clicks, float *propensities, void *stream)
 {
+    LTR_CLEAR_STALE_ERROR();
     if (B < 0 || L <= 0 || n_probs <= 0) return LTR_ERR_SHAPE;
     if (B == 0) return LTR_OK;
     if (!rankings || !ys || !n || !relevance_probs || !u || !clicks || !propensities) return LTR_ERR_NULL;
@@ -2233,6 +2255,7 @@ int ltr_collate_pad_f32(const float *xs, const int64_t *ys, const int64_t *offse
                         const int64_t *qidx, const int64_t *sel, int Q, int B, int L, int F,
                         float *out_x, int64_t *out_y, int64_t *out_n, void *stream)
 {
+    LTR_CLEAR_STALE_ERROR();
     if (B < 0 || L <= 0 || F <= 0 || Q <= 0) return LTR_ERR_SHAPE;
     if (B == 0) return LTR_OK;
     if (!xs || !ys || !offsets || !qidx || !out_x || !out_y || !out_n) return LTR_ERR_NULL;

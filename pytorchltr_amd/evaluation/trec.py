@@ -18,7 +18,7 @@ def generate_pytrec_eval(scores: _torch.Tensor, relevance: _torch.Tensor, n: _to
     given ``qids`` or the row index plus ``qid_offset``), document ids ``d_prefix + position``,
     and only the first ``n[i]`` documents of a row are listed."""
     batch = scores.shape[0]
-    score_rows = scores.detach().reshape(batch, -1).float().cpu().tolist()
+    score_rows = scores.detach().reshape(batch, -1).cpu().tolist()      # at the input's precision, like float(scores[i, d])
     label_rows = relevance.detach().reshape(batch, -1).cpu().tolist()
     counts = n.detach().reshape(-1).cpu().tolist()
     ids = None if qids is None else qids.detach().reshape(-1).cpu().tolist()

@@ -19,14 +19,18 @@ def mask_padded_values(xs: _torch.FloatTensor, n: _torch.LongTensor,
                        mutate: bool = False):
     """Sets entries j >= n[b] of every row to `mask_value` (reference :6-26).
 
-    With mutate=True, `xs` (fp32, contiguous) is overwritten in place and returned."""
+    With mutate=True, `xs` is overwritten in place and returned (any dtype / layout; contiguous
+    fp32 takes the HIP kernel)."""
     _C.require_device(xs, "xs")
     x2 = _as_2d(xs, "xs")
     nn = _prepare_n(n, x2.shape[0])
     B, L = x2.shape
+    if mutate and (xs.dtype != _torch.float32 or not xs.is_contiguous()):
+        # any other dtype / layout: the same in-place masking with device-side torch ops
+        cols = _torch.arange(L, device=xs.device).reshape(1, L)
+        x2.masked_fill_(cols >= nn.reshape(B, 1), mask_value)
+        return xs
     if mutate:
-        if xs.dtype != _torch.float32 or not xs.is_contiguous():
-            raise TypeError("mutate=True needs a contiguous float32 tensor")
         src, out = x2, x2
     else:
         src = _prepare_scores(xs)

@@ -190,3 +190,22 @@ def test_sort_by_length_reorders_whole_queries():
         k = int(srt.n[row])
         assert torch.equal(srt.features[row, :k], plain.features[src, :k])
         assert torch.equal(srt.relevance[row, :k], plain.relevance[src, :k])
+
+
+@pytest.mark.gpu
+def test_query_indices_are_validated():
+    """out-of-range indices raise IndexError (negative ones count from the end) instead
+    of being clamped by the kernel."""
+    import torch
+    from pytorchltr_amd.datasets import RaggedQueries
+    X = torch.arange(12, dtype=torch.float32).reshape(6, 2)
+    y = torch.tensor([1, 0, 2, 0, 1, 1])
+    ds = RaggedQueries(X, y, [0, 2, 3, 6], device="cuda:0")
+    assert ds[-1] == 2 and ds[0] == 0
+    b = ds.collate([-1, 0])
+    assert b.n.cpu().tolist() == [3, 2]
+    for bad in (3, -4, 100):
+        with pytest.raises(IndexError):
+            ds[bad]
+        with pytest.raises(IndexError):
+            ds.collate([0, bad])

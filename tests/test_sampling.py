@@ -151,3 +151,34 @@ def test_click_simulators_monte_carlo_like_the_reference_tests():
     want_p = torch.tensor([[1 / 4.0, 1 / 6.0, 1 / 5.0, 1 / 2.0, 1 / 3.0], [1 / 3.0, 1 / 2.0, 1 / 4.0, 0.0, 0.0]])
     assert props.numpy() == pytest.approx(want_p.numpy(), abs=1e-6)
     assert clicks.numpy() == pytest.approx((rel * want_p).numpy(), abs=0.1)
+
+
+@pytest.mark.gpu
+def test_pbm_rejects_labels_and_rankings_out_of_range():
+    """the reference's gathers raise on bad indices; no silent clamping here either."""
+    import torch
+    from pytorchltr_amd.click_simulation import simulate_pbm
+    dev = torch.device("cuda:0")
+    rk = torch.tensor([[0, 1, 2]], device=dev)
+    n = torch.tensor([3], device=dev)
+    probs = torch.tensor([0.1, 0.5], device=dev)
+    simulate_pbm(rk, torch.tensor([[0, 1, 1]], device=dev), n, probs)
+    with pytest.raises(IndexError):
+        simulate_pbm(rk, torch.tensor([[0, 2, 1]], device=dev), n, probs)          # label 2: no probability
+    with pytest.raises(IndexError):
+        simulate_pbm(torch.tensor([[0, 1, 3]], device=dev), torch.tensor([[0, 1, 1]], device=dev), n, probs)
+
+
+@pytest.mark.gpu
+def test_mask_padded_values_mutates_any_dtype():
+    import torch
+    from pytorchltr_amd.utils import mask_padded_values
+    dev = torch.device("cuda:0")
+    n = torch.tensor([1, 3], device=dev)
+    for dtype in (torch.float64, torch.float16, torch.float32):
+        x = torch.ones(2, 3, dtype=dtype, device=dev)
+        out = mask_padded_values(x, n, mask_value=0.0, mutate=True)
+        assert out is x and x.cpu().tolist() == [[1.0, 0.0, 0.0], [1.0, 1.0, 1.0]]
+    xt = torch.ones(3, 2, device=dev).t()                                            # non-contiguous view
+    mask_padded_values(xt, n, mask_value=-1.0, mutate=True)
+    assert xt.cpu().tolist() == [[1.0, -1.0, -1.0], [1.0, 1.0, 1.0]]

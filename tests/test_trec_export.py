@@ -34,3 +34,15 @@ def test_explicit_qids_and_trailing_unit_dim():
     assert run["49998"] == {"d0": 5.0, "d1": 6.0, "d2": 4.0, "d3": 2.0}
     assert all(isinstance(v, int) for v in qrels["15623"].values())
     assert all(isinstance(v, float) for v in run["15623"].values())
+
+
+def test_scores_keep_their_input_precision():
+    """the reference exports float(scores[i, d]) at the input's precision."""
+    import torch
+    from pytorchltr_amd.evaluation import generate_pytrec_eval
+    s = torch.tensor([[0.1234567890123, 2.0]], dtype=torch.float64)
+    qrel, run = generate_pytrec_eval(s, torch.tensor([[1, 0]]), torch.tensor([2]))
+    assert run["q0"]["d0"] == 0.1234567890123                  # not rounded through fp32
+    s32 = s.float()
+    _, run32 = generate_pytrec_eval(s32, torch.tensor([[1, 0]]), torch.tensor([2]))
+    assert run32["q0"]["d0"] == float(s32[0, 0])
