@@ -797,10 +797,15 @@ __device__ __forceinline__ float wave_rol1(float v)
 #ifndef LTR_SYM_MIN_STEPS
 #define LTR_SYM_MIN_STEPS 1
 #endif
+#ifdef LTR_TRACE
+#define LTR_SYM_STAMP(i) do { if (trace && threadIdx.x == 0) trace[i] = (long long)wall_clock64(); } while (0)
+#else
+#define LTR_SYM_STAMP(i) do { } while (0)
+#endif
 template <int KIND, int TW = 0>
 __device__ __forceinline__ float pairwise_core_sym(const QueryLds &q, int nb, int Lt, float sigma,
                                                    float &gscale, int part = 0, int parts = 1,
-                                                   bool raw = false)
+                                                   bool raw = false, long long *trace = nullptr)
 {
     const int tid = threadIdx.x;
     const int T = TW > 0 ? TW * 64 : (int)blockDim.x;
@@ -859,6 +864,7 @@ __device__ __forceinline__ float pairwise_core_sym(const QueryLds &q, int nb, in
         }
     }
     int j = ((a == b) ? 1 : 0) + rem;
+    LTR_SYM_STAMP(0);                                        // slices zeroed, units decoded
 
     while (u < u1) {
         const bool diag = (a == b);
@@ -957,6 +963,7 @@ __device__ __forceinline__ float pairwise_core_sym(const QueryLds &q, int nb, in
     }
     if (kRowWeight && part == 0)              // the i == j terms: a_i * log2(1 + e^0) = a_i
         for (int k = tid; k < nb; k += T) lacc += q.sy[k].y;
+    LTR_SYM_STAMP(1);                                        // steps done, accumulators flushed (wave 0)
 
     float total;
     if (TW > 0) {
@@ -965,6 +972,7 @@ __device__ __forceinline__ float pairwise_core_sym(const QueryLds &q, int nb, in
         const float ws = wave_sum(lacc);
         if (lane == 0) q.red[16 + wl] = ws;
         __syncthreads();
+        LTR_SYM_STAMP(2);                                    // barrier passed
         total = 0.f;
 #pragma unroll
         for (int i = 0; i < (TW > 0 ? TW : 1); ++i) total += q.red[16 + i];
@@ -984,14 +992,16 @@ __device__ __forceinline__ float pairwise_core_sym(const QueryLds &q, int nb, in
     return total;
 }
 
-template <int KIND, int DPT>
-__global__ void __launch_bounds__(1024)
+// NW > 0 (symmetric pass only): the workgroup has NW waves, known at compile time (4 / 8 / 16 by
+// list length) -- the pair pass then needs no dispatch-packet read, no divisions and one barrier less.
+template <int KIND, int DPT, int NW = 0>
+__global__ void __launch_bounds__(NW > 0 ? NW * 64 : 1024)
 pairwise_loss_kernel(LossParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int L = p.L;
     const int tid = threadIdx.x;
-    const int T = blockDim.x;
+    const int T = NW > 0 ? NW * 64 : (int)blockDim.x;
     int b, nb;
     if (p.sched) {
         b = sched_query_sampled(p.n, p.B, L, p.sched, tid, nb, (int)blockIdx.x);
@@ -1032,7 +1042,7 @@ pairwise_loss_kernel(LossParams p)
             const int m1 = __builtin_amdgcn_readfirstlane(min(nb, m0 + mlen));
             prepare_ndcg<KIND, 1>(q, nb, owners, tid % owners, m0, m1, ms > 1);
         }
-        total = pairwise_core_sym<KIND>(q, nb, L4, p.sigma, gscale);
+        total = pairwise_core_sym<KIND, NW>(q, nb, L4, p.sigma, gscale);
         gsum = 0.f;
     } else {
         total = pairwise_core<KIND, (DPT > 0 ? DPT : 1)>(q, nb, L4, msplit, p.sigma, gscale, gsum);
@@ -1778,14 +1788,27 @@ int launch_loss_kind(const LossParams &p, const LaunchShape &s, hipStream_t stre
         LTR_ENSURE_LDS((pairwise_loss_kernel<KIND, D>), lds);          \
         hipLaunchKernelGGL((pairwise_loss_kernel<KIND, D>), grid, block, lds, stream, p);       \
     } while (0)
+#define LTR_LAUNCH_SYM(NWAVES)                                                                   \
+    do {                                                                                        \
+        LTR_ENSURE_LDS((pairwise_loss_kernel<KIND, 0, NWAVES>), lds);                           \
+        hipLaunchKernelGGL((pairwise_loss_kernel<KIND, 0, NWAVES>), grid, block, lds, stream, p); \
+    } while (0)
     switch (s.dpt) {
-    case 0: LTR_LAUNCH(0); break;
+    case 0:
+        // the shapes choose_loss_shape picks get a compile-time wave count; explicit (_cfg) shapes
+        // with another block size run the run-time variant
+        if (s.owners * s.msplit == 256) LTR_LAUNCH_SYM(4);
+        else if (s.owners * s.msplit == 512) LTR_LAUNCH_SYM(8);
+        else if (s.owners * s.msplit == 1024) LTR_LAUNCH_SYM(16);
+        else LTR_LAUNCH(0);
+        break;
     case 1: LTR_LAUNCH(1); break;
     case 2: LTR_LAUNCH(2); break;
     case 4: LTR_LAUNCH(4); break;
     default: return LTR_ERR_CONFIG;
     }
 #undef LTR_LAUNCH
+#undef LTR_LAUNCH_SYM
     return (int)hipGetLastError();
 }
 

@@ -96,6 +96,10 @@ def main():
     # phase durations averaged over all workgroups of the last launch
     d = ts[:, 1:] - ts[:, :-1]
     print("phase mean ns: " + "  ".join("%s %.0f" % (nm, v) for nm, v in zip(names[1:], d.mean(0))))
+    # inside the pair pass (wave 0): setup | steps + flush | barrier | rest, from the extra stamps 8..10
+    tt = t.double()
+    inner = torch.stack([tt[:, 8] - tt[:, 3], tt[:, 9] - tt[:, 8], tt[:, 10] - tt[:, 9], tt[:, 4] - tt[:, 10]], dim=1) * 10.0
+    print("pair pass inner mean ns (wave 0): setup %.0f  steps+flush %.0f  sum+barrier %.0f  tail %.0f" % tuple(inner.mean(0).tolist()))
     # per-CU occupancy picture of the last launch: workgroups per (xcc, se, cu)
     hw = (meta >> 32) & 0xffff
     xcc = (meta >> 48) & 0xf
