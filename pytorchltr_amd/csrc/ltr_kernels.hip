@@ -561,12 +561,13 @@ __device__ __forceinline__ QueryLds carve_query_lds(unsigned char *base, int L4,
 
 // NDCG kinds: ranks by score and by label, maxDCG, gains.  On return (barrier passed)
 //   NDCG1: sy[k].y = a_k = G_k / log2(2 + rank_k);   NDCG2: q4[k] = (s, y, G, rank), delta table.
-template <int KIND, int DPT>
+// TW > 0: the workgroup has TW waves (compile-time): the maxDCG sum takes one barrier instead of two.
+template <int KIND, int DPT, int TW = 0>
 __device__ __forceinline__ void prepare_ndcg(const QueryLds &q, int nb, int owners, int o, int m0,
                                              int m1, bool partial)
 {
     const int tid = threadIdx.x;
-    const int T = blockDim.x;
+    const int T = TW > 0 ? TW * 64 : (int)blockDim.x;
     float2 *sy = q.sy;
     // Lists longer than kSortRankMinLen: both rankings by a bitonic sort of packed (key, index)
     // words (see sort_ranks) when the exchange buffer fits behind the rank arrays in the gpart
@@ -612,7 +613,17 @@ __device__ __forceinline__ void prepare_ndcg(const QueryLds &q, int nb, int owne
     float part = 0.f;
     for (int k = tid; k < nb; k += T)
         part += (exp2f(sy[k].y) - 1.0f) / log2f(2.0f + (float)q.rank_y[k]);
-    float maxdcg = block_sum(part, q.red);
+    float maxdcg;
+    if (TW > 0) {
+        const float ws = wave_sum(part);
+        if ((tid & 63) == 0) q.red[tid >> 6] = ws;
+        __syncthreads();
+        maxdcg = 0.f;
+#pragma unroll
+        for (int i = 0; i < (TW > 0 ? TW : 1); ++i) maxdcg += q.red[i];
+    } else {
+        maxdcg = block_sum(part, q.red);
+    }
     if (maxdcg == 0.0f) maxdcg = 1.0f;                     // pairwise_lambda.py:227
     const float inv_maxdcg = 1.0f / maxdcg;
     for (int k = tid; k < nb; k += T) {
@@ -892,6 +903,11 @@ __device__ __forceinline__ float pairwise_core_sym(const QueryLds &q, int nb, in
             }
         }
         float gh = 0.f, gv = 0.f;
+        // LambdaNDCG2: the discount difference delta(|rank_home - rank_visitor|) comes from an LDS
+        // table; it is fetched ONE STEP AHEAD (the next visitor's rank is one rotation away), so the
+        // LDS round trip is off the dependency chain of the step (the pass is latency-bound)
+        float dcur = 0.f;
+        if (KIND == LTR_NDCG2) dcur = q.delta[(int)fabsf(rh - rv)];
 
         // one evaluation of the pair (home, visitor); `half`: only lanes < 32 count (j == 32)
         auto visit = [&](bool half) {
@@ -913,7 +929,7 @@ __device__ __forceinline__ float pairwise_core_sym(const QueryLds &q, int nb, in
                 const bool gt = yh > yv, lt = yh < yv;
                 float Wp = 1.0f;
                 if (KIND == LTR_ARP2) Wp = fabsf(yh - yv);
-                if (KIND == LTR_NDCG2) Wp = q.delta[(int)fabsf(rh - rv)] * fabsf(Gh - Gv);
+                if (KIND == LTR_NDCG2) Wp = dcur * fabsf(Gh - Gv);
                 const float t = (sh - sv) * c1;
                 const float z = gt ? t : -t;
                 const float e = __builtin_amdgcn_exp2f(-fabsf(z));
@@ -947,7 +963,13 @@ __device__ __forceinline__ float pairwise_core_sym(const QueryLds &q, int nb, in
         const int jstop = j + steps;
         // full steps (every lane), then at most one half step (diagonal job, j == 32)
         const int jfull = diag ? min(jstop, 32) : jstop;
-        for (; j < jfull; ++j) { visit(false); rotate(); }
+        for (; j < jfull; ++j) {
+            float dnext = 0.f;
+            if (KIND == LTR_NDCG2) dnext = q.delta[(int)fabsf(rh - wave_rol1(rv))];
+            visit(false);
+            rotate();
+            dcur = dnext;
+        }
         if (j < jstop) { visit(true); rotate(); ++j; }
 
         // ---- flush both accumulators into this wave's private slice ----
@@ -1040,7 +1062,7 @@ pairwise_loss_kernel(LossParams p)
             const int mlen = (nb + ms - 1) / ms;
             const int m0 = __builtin_amdgcn_readfirstlane(min(nb, (tid / owners) * mlen));
             const int m1 = __builtin_amdgcn_readfirstlane(min(nb, m0 + mlen));
-            prepare_ndcg<KIND, 1>(q, nb, owners, tid % owners, m0, m1, ms > 1);
+            prepare_ndcg<KIND, 1, NW>(q, nb, owners, tid % owners, m0, m1, ms > 1);
         }
         total = pairwise_core_sym<KIND, NW>(q, nb, L4, p.sigma, gscale);
         gsum = 0.f;
