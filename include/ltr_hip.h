@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LTR_VERSION 110 /* 0.1.1 */
+#define LTR_VERSION 111 /* 0.1.11 */
 
 /* Loss kinds: one per class exported by pytorchltr/loss/__init__.py:1-7. */
 enum ltr_loss_kind {
@@ -83,6 +83,10 @@ int ltr_max_list_len_f64(void);
 int ltr_device_status(int clear);
 /* Tests only: != 0 makes every in-launch wait of the cluster kernel give up at once. */
 void ltr_debug_force_timeout(int on);
+/* Tests / measurements only: which kernel layout ltr_mlp_pairwise_f32 takes where both apply.
+ * 0 = default (4-wave tile kernel, csrc/ltr_mlp2.inc), 1 = the 8-wave kernel of csrc/ltr_mlp.inc.
+ * LTR_MLP_LAYOUT in the environment sets the initial value. */
+void ltr_debug_mlp_layout(int layout);
 
 /*
  * Seven pairwise losses, forward + analytic gradient in ONE pass.

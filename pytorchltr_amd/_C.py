@@ -9,7 +9,8 @@ import os
 import torch  # noqa: F401  (loads the HIP runtime the extension binds to, before dlopen)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libltr_hip.so")
+# LTR_HIP_LIB: another build of the same library (tuning variants, scripts/build_variants.sh)
+LIB_PATH = os.environ.get("LTR_HIP_LIB") or os.path.join(_HERE, "csrc", "libltr_hip.so")
 
 # enum ltr_loss_kind
 HINGE, DCG_HINGE, LOGISTIC, ARP1, ARP2, NDCG1, NDCG2 = range(7)
@@ -29,6 +30,7 @@ SIGNATURES = {
     "ltr_max_list_len_f64": (_i, []),
     "ltr_device_status": (_i, [_i]),
     "ltr_debug_force_timeout": (None, [_i]),
+    "ltr_debug_mlp_layout": (None, [_i]),
     "ltr_pairwise_loss_f32": (_i, [_i, _f, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "ltr_pairwise_loss_f32_cfg": (_i, [_i, _f, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     "ltr_pairwise_loss_workspace_bytes": (_sz, [_i, _i, _i]),

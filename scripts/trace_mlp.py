@@ -19,14 +19,24 @@ PHASES = ["weights->LDS", "labels", "layer1 MFMA", "layers 2,3 + barrier", "pair
           "(sched) prefix", "(sched) rank"]
 
 
+PHASES_TILE = ["rest of prologue", "(fwd) next fill issue + barrier", "layer-1 tile + L2 partial", "owner: layers 2,3",
+               "pair pass", "bwd: refill + dH2 rows", "bwd GEMMs (dW2, dH1, dW1)", "partial vector",
+               "(prologue) fragment loads", "(prologue) scheduling", "(fwd) owner + parking of fill before",
+               "(fwd) wait for P + image write"]
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--layout", default="tile", choices=["tile", "wide"],
+                    help="tile = 4-wave kernel of ltr_mlp2.inc (default dispatch), wide = LTR_MLP_LAYOUT=1")
     ap.add_argument("--lib", default=os.path.join(ROOT, "build", "variants", "libltr_mlptrace.so"))
     ap.add_argument("--kind", default="hinge")
     ap.add_argument("--full-lists", action="store_true")
     ap.add_argument("--B", type=int, default=1024)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
+    if args.layout == "wide":
+        os.environ["LTR_MLP_LAYOUT"] = "1"
     lib = ctypes.CDLL(args.lib)
     for name, (res, argt) in _C.SIGNATURES.items():
         getattr(lib, name).restype = res
@@ -52,10 +62,12 @@ def main():
         assert rc == 0, rc
         torch.cuda.synchronize()
     t = trace.view(grid, 16).double().cpu()
+    t = t[t.sum(1) > 0]                      # (the workspace is sized for the larger grid)
+    grid = t.shape[0]
     tot = t[:, :14].sum(1)
     print("workgroups %d, queries/workgroup %.1f; total cycles/workgroup mean %.0f max %.0f" % (
         grid, B / grid, tot.mean(), tot.max()))
-    for i, name in enumerate(PHASES):
+    for i, name in enumerate(PHASES_TILE if args.layout == "tile" else PHASES):
         print("  %-24s mean %9.0f  (%5.1f%%)   max %9.0f" % (name, t[:, i].mean(), 100 * t[:, i].mean() / tot.mean(), t[:, i].max()))
 
 

@@ -17,6 +17,17 @@ pytestmark = pytest.mark.gpu
 KINDS = ("hinge", "dcg_hinge", "logistic", "arp1", "arp2", "ndcg1", "ndcg2")
 
 
+@pytest.fixture(params=["tile", "wide"], autouse=True)
+def _mlp_layout(request):
+    """Every test of this file runs on both kernel layouts of the training step: the 4-wave tile
+    kernel (csrc/ltr_mlp2.inc, the default for F <= 144) and the 8-wave kernel (csrc/ltr_mlp.inc,
+    which also serves wider feature rows and the forward-only scores)."""
+    from pytorchltr_amd import _C
+    _C.lib().ltr_debug_mlp_layout(1 if request.param == "wide" else 0)
+    yield
+    _C.lib().ltr_debug_mlp_layout(0)
+
+
 def _mlp_params(F, H1, H2, seed):
     g = torch.Generator().manual_seed(seed)
 
