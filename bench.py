@@ -337,7 +337,7 @@ def mlp_extra(kind, batches, no_graph):
     us, _ = time_launches(launch, nbuf, rounds=2, replays=10)
     docs = sum(b["rows"] for b in batches) / float(nbuf)
     flops_per_doc = 2 * (F * H1 + H1 * H2 + H2) + 2 * (F * H1 + 2 * H1 * H2 + H2)   # fwd + bwd, no dX
-    out = {"step": "MLP %d-%d-%d-1 + %s fwd+bwd (2 launches: mlp_pairwise_kernel + mlp_reduce_kernel), "
+    out = {"step": "MLP %d-%d-%d-1 + %s fwd+bwd (2 launches: mlp_tile_kernel + mlp_reduce_kernel), "
                    "%d rotating batches" % (F, H1, H2, kind, nbuf),
            "us_per_step": us, "queries_per_s": B / (us * 1e-6),
            "useful_TFLOPs": docs * flops_per_doc / (us * 1e-6) / 1e12,
