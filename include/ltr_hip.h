@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LTR_VERSION 111 /* 0.1.11 */
+#define LTR_VERSION 112 /* 0.1.12 */
 
 /* Loss kinds: one per class exported by pytorchltr/loss/__init__.py:1-7. */
 enum ltr_loss_kind {
@@ -290,8 +290,10 @@ int ltr_linear_reduce_accum_f32(const float *partials, const float *grad_out, co
  *   loss (B); scores_out (B,L) or NULL (written for documents < n[b] only);
  *   grads: ltr_mlp_param_count(F,H1,H2) floats = [dW1 | db1 | dW2 | db2 | dW3 | db3], the gradient
  *   of sum_b grad_out[b] * loss[b];  loss_sum[0] = sum_b loss[b] or NULL.
- * Shape limits of this kernel: L <= 128 (LTR_ERR_LIST_TOO_LONG), F % 4 == 0, F <= 224, H1 <= 64,
- * H2 <= 16 (LTR_ERR_SHAPE).  workspace: ltr_mlp_workspace_bytes(B,F,H1,H2) bytes. */
+ * Shape limits of this kernel: L <= ltr_mlp_max_list_len(F) = 256 for F <= 144, 128 for wider rows
+ * (LTR_ERR_LIST_TOO_LONG), F % 4 == 0, F <= 224, H1 <= 64, H2 <= 16 (LTR_ERR_SHAPE).
+ * workspace: ltr_mlp_workspace_bytes(B,F,H1,H2) bytes. */
+int ltr_mlp_max_list_len(int F);
 size_t ltr_mlp_param_count(int F, int H1, int H2);
 size_t ltr_mlp_workspace_bytes(int B, int F, int H1, int H2);
 int ltr_mlp_pairwise_f32(int kind, float sigma, const float *X, const float *W1, const float *b1,

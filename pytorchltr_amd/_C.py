@@ -63,6 +63,7 @@ SIGNATURES = {
     "ltr_linear_scores_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ltr_linear_grad_workspace_bytes": (_sz, [_i, _i, _i]),
     "ltr_linear_grad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "ltr_mlp_max_list_len": (_i, [_i]),
     "ltr_mlp_param_count": (_sz, [_i, _i, _i]),
     "ltr_mlp_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ltr_mlp_scores_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -294,14 +294,22 @@ class LinearScorer(torch.nn.Module):
 # ---------------------------------------------------------------------------------------------
 # ReLU MLP scorer (the network of the reference's guide) fused with the loss -- SURVEY.md 8 f-2
 # ---------------------------------------------------------------------------------------------
-MLP_MAX_LIST_LEN = 128
+MLP_MAX_LIST_LEN = 128           # feature rows wider than 144 floats
+MLP_MAX_LIST_LEN_NARROW = 256    # F <= 144
+MLP_NARROW_FEATURES = 144
 MLP_MAX_FEATURES = 224
 MLP_MAX_HIDDEN = (64, 16)
 
 
+def mlp_max_list_len(F):
+    """Longest list the fused MLP kernels take at F features: 256 for F <= 144 (the tile kernel),
+    128 for wider rows (ltr_mlp_max_list_len)."""
+    return MLP_MAX_LIST_LEN_NARROW if F <= MLP_NARROW_FEATURES else MLP_MAX_LIST_LEN
+
+
 def mlp_supported(L, F, H1, H2):
     """Shapes the fused MLP kernel takes (see include/ltr_hip.h: ltr_mlp_pairwise_f32)."""
-    return (0 < L <= MLP_MAX_LIST_LEN and 0 < F <= MLP_MAX_FEATURES and F % 4 == 0
+    return (0 < F <= MLP_MAX_FEATURES and F % 4 == 0 and 0 < L <= mlp_max_list_len(F)
             and 0 < H1 <= MLP_MAX_HIDDEN[0] and 0 < H2 <= MLP_MAX_HIDDEN[1])
 
 
@@ -356,9 +364,10 @@ def mlp_loss_step(xs, params, relevance, n, loss="hinge", grad_out=None, return_
     B, L, F = X.shape
     flat_params, H1, H2 = _flat_params(params, F)
     if not mlp_supported(L, F, H1, H2):
-        raise ValueError("fused MLP kernel takes L <= %d, F <= %d with F %% 4 == 0, hidden <= %s; "
-                         "got L=%d F=%d hidden=(%d, %d)" % (MLP_MAX_LIST_LEN, MLP_MAX_FEATURES,
-                                                            MLP_MAX_HIDDEN, L, F, H1, H2))
+        raise ValueError("fused MLP kernel takes L <= %d (F <= 144: %d), F <= %d with F %% 4 == 0, "
+                         "hidden <= %s; got L=%d F=%d hidden=(%d, %d)"
+                         % (MLP_MAX_LIST_LEN, MLP_MAX_LIST_LEN_NARROW, MLP_MAX_FEATURES,
+                            MLP_MAX_HIDDEN, L, F, H1, H2))
     r = prepare_relevance(relevance, X[:, :, 0])
     nn = prepare_n(n, B)
     lib = _C.lib()
@@ -393,8 +402,9 @@ def mlp_scores(xs, params, n=None):
     B, L, F = X.shape
     flat_params, H1, H2 = _flat_params(params, F)
     if not mlp_supported(L, F, H1, H2):
-        raise ValueError("fused MLP kernel takes L <= %d, F <= %d with F %% 4 == 0, hidden <= %s"
-                         % (MLP_MAX_LIST_LEN, MLP_MAX_FEATURES, MLP_MAX_HIDDEN))
+        raise ValueError("fused MLP kernel takes L <= %d (F <= 144: %d), F <= %d with F %% 4 == 0, "
+                         "hidden <= %s" % (MLP_MAX_LIST_LEN, MLP_MAX_LIST_LEN_NARROW, MLP_MAX_FEATURES,
+                                           MLP_MAX_HIDDEN))
     nn = (torch.full((B,), L, dtype=torch.int64, device=X.device) if n is None else prepare_n(n, B))
     scores = torch.empty(B, L, dtype=torch.float32, device=X.device)
     if B > 0:
@@ -452,7 +462,7 @@ class FusedMLPLoss(torch.nn.Module):
     fills the six parameter gradients -- computed by one fused MFMA kernel.
 
     Feature counts that are not a multiple of 4 are zero-padded on the fly.  Shapes the kernel
-    does not take (lists longer than 128, more than 224 features, ...) run as the unfused
+    does not take (lists longer than 256 -- 128 beyond 144 features --, more than 224 features, ...) run as the unfused
     composition: rocBLAS layers + the HIP loss kernel.  ``score(xs)`` evaluates the
     network alone (for the metrics).
     """

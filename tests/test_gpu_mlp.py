@@ -178,10 +178,48 @@ def test_module_matches_unfused_composition(reduction):
         assert torch.allclose(a.grad, b.grad, rtol=2e-4, atol=2e-5 * max(1.0, scale))
 
 
+@pytest.mark.parametrize("shape", [(7, 160, 136, 50, 10), (5, 256, 136, 50, 10), (6, 200, 24, 13, 5),
+                                   (3, 129, 80, 64, 16)])
+def test_lists_of_129_to_256_documents(shape, request):
+    """F <= 144: lists up to 256 documents run on the tile kernel (no parking: the forward pass of
+    a fill runs again in the backward pass); all seven kinds at the guide's network."""
+    if "wide" in request.node.name:
+        pytest.skip("the 8-wave layout stops at 128 documents")
+    B, L, F, H1, H2 = shape
+    case = _case(B, L, F, H1, H2, 300 + L)
+    case[2][0] = L                       # a full list
+    case[2][1] = 129                     # one document in the fifth fill
+    kinds = KINDS if F == 136 and L == 160 else ("hinge", "logistic", "ndcg2")
+    for kind in kinds:
+        _check(kind, *case)
+    g = torch.Generator().manual_seed(L)
+    _check("arp1", *case, grad_out=torch.rand(B, generator=g) + 0.1)
+
+
+def test_scores_of_lists_of_129_to_256_documents():
+    from pytorchltr_amd import fused
+    dev = torch.device("cuda")
+    B, L, F, H1, H2 = 40, 256, 136, 50, 10
+    X, y, n, params = _case(B, L, F, H1, H2, 77)
+    n[0] = L
+    n[1] = 0
+    n[2] = 129
+    P = [p.to(dev) for p in params]
+    Xd = X.to(dev)
+    h = torch.relu(Xd @ P[0].t() + P[1])
+    h = torch.relu(h @ P[2].t() + P[3])
+    want = (h @ P[4].t() + P[5]).squeeze(-1)
+    got = fused.mlp_scores(Xd, P, n.to(dev))
+    valid = (torch.arange(L)[None, :] < n[:, None]).to(dev)
+    assert torch.allclose(got[valid], want[valid], rtol=1e-5, atol=2e-6)
+    assert not got[~valid].any()
+    assert torch.allclose(fused.mlp_scores(Xd, P), want, rtol=1e-5, atol=2e-6)
+
+
 def test_module_long_lists_take_the_unfused_path():
     from pytorchltr_amd.fused import FusedMLPLoss
     dev = torch.device("cuda")
-    X, y, n, _ = _case(3, 200, 24, 50, 10, 4)
+    X, y, n, _ = _case(3, 300, 24, 50, 10, 4)
     m = FusedMLPLoss(24, "hinge").to(dev)
     out = m(X.to(dev), y.to(dev), n.to(dev))
     out.backward()
@@ -197,8 +235,11 @@ def test_argument_errors():
         fused.mlp_loss_step(X.to(dev), [p.to(dev) for p in params], y.to(dev), n.to(dev))
     lib = _C.lib()
     z = ctypes.c_void_p(8)
-    assert lib.ltr_mlp_pairwise_f32(0, 1.0, z, z, z, z, z, z, z, z, 0, z, None, 1, 129, 8, 4, 4, z, None,
+    assert lib.ltr_mlp_max_list_len(136) == 256 and lib.ltr_mlp_max_list_len(200) == 128
+    assert lib.ltr_mlp_pairwise_f32(0, 1.0, z, z, z, z, z, z, z, z, 0, z, None, 1, 257, 8, 4, 4, z, None,
                                     z, None, z, 1 << 30, None) == -4        # LTR_ERR_LIST_TOO_LONG
+    assert lib.ltr_mlp_pairwise_f32(0, 1.0, z, z, z, z, z, z, z, z, 0, z, None, 1, 129, 200, 4, 4, z, None,
+                                    z, None, z, 1 << 30, None) == -4        # (wide rows: 128)
     assert lib.ltr_mlp_pairwise_f32(0, 1.0, z, z, z, z, z, z, z, z, 0, z, None, 1, 16, 8, 65, 4, z, None,
                                     z, None, z, 1 << 30, None) == -2        # LTR_ERR_SHAPE
     assert lib.ltr_mlp_pairwise_f32(0, 1.0, z, z, z, z, z, z, z, z, 0, z, None, 1, 16, 8, 4, 4, z, None,
