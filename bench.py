@@ -361,6 +361,25 @@ def mlp_extra(kind, batches, no_graph):
         unfused()
     torch.cuda.synchronize()
     out["unfused_torch_layers_plus_loss_module_eager_us"] = (time.perf_counter() - t0) / 30 * 1e6
+
+    # the drop-in module of the guide's step (FusedMLPLoss: nn.Linear parameters, autograd), eager:
+    # what a training script gets per `loss = model(xs, ys, n); loss.backward()`
+    def module_step(i):
+        b = batches[i % nbuf]
+        for p_ in ps:
+            p_.grad = None
+        m(b["X"], b["rel"], b["n"]).backward()
+    for i in range(10):
+        module_step(i)
+    torch.cuda.synchronize()
+    reps = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for i in range(40):
+            module_step(i)
+        torch.cuda.synchronize()
+        reps.append((time.perf_counter() - t0) / 40 * 1e6)
+    out["fused_module_autograd_eager_us"] = sorted(reps)[len(reps) // 2]
     return out
 
 

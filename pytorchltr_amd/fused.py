@@ -324,7 +324,9 @@ def _pad_features(xs, w1):
 
 
 def _flat_params(params, F):
-    W1, b1, W2, b2, W3, b3 = [t.detach().float().contiguous() for t in params]
+    # (fp32 contiguous tensors -- nn.Linear parameters -- go to the C ABI as they are)
+    W1, b1, W2, b2, W3, b3 = [t if (t.dtype is torch.float32 and t.is_contiguous())
+                              else t.detach().float().contiguous() for t in params]
     H1, H2 = W1.shape[0], W2.shape[0]
     if W1.shape != (H1, F) or b1.numel() != H1 or W2.shape != (H2, H1) or b2.numel() != H2 \
             or W3.numel() != H2 or b3.numel() != 1:
@@ -333,13 +335,35 @@ def _flat_params(params, F):
 
 
 def _split_grads(flat, F, H1, H2):
-    sizes = (H1 * F, H1, H2 * H1, H2, H2, 1)
-    shapes = ((H1, F), (H1,), (H2, H1), (H2,), (1, H2), (1,))
-    out, o = [], 0
-    for size, shape in zip(sizes, shapes):
-        out.append(flat[o:o + size].view(shape))
-        o += size
-    return tuple(out)
+    """The six gradient tensors as views of the flat buffer [dW1 | db1 | dW2 | db2 | dW3 | db3]."""
+    w1, b1, w2, b2, w3, b3 = flat.split((H1 * F, H1, H2 * H1, H2, H2, 1))
+    return (w1.view(H1, F), b1, w2.view(H2, H1), b2, w3.view(1, H2), b3)
+
+
+_mlp_sizes = {}          # (B, F, H1, H2) -> (parameter count, workspace bytes)
+_mlp_workspaces = {}     # (device index, stream, bytes) -> scratch tensor (consumed in stream order)
+
+
+def _mlp_sizes_for(B, F, H1, H2):
+    key = (B, F, H1, H2)
+    v = _mlp_sizes.get(key)
+    if v is None:
+        lib = _C.lib()
+        v = _mlp_sizes[key] = (int(lib.ltr_mlp_param_count(F, H1, H2)),
+                               int(lib.ltr_mlp_workspace_bytes(B, F, H1, H2)))
+    return v
+
+
+def _mlp_workspace(dev, stream, ws_bytes):
+    """The per-workgroup partial vectors (15 MB at the guide's network) live only between the two
+    launches of one call, which run in stream order: one buffer per (device, stream) is reused."""
+    key = (dev.index, stream, ws_bytes)
+    ws = _mlp_workspaces.get(key)
+    if ws is None:
+        if len(_mlp_workspaces) > 16:
+            _mlp_workspaces.clear()
+        ws = _mlp_workspaces[key] = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=dev)
+    return ws
 
 
 def mlp_loss_step(xs, params, relevance, n, loss="hinge", grad_out=None, return_scores=False,
@@ -368,24 +392,32 @@ def mlp_loss_step(xs, params, relevance, n, loss="hinge", grad_out=None, return_
                          "hidden <= %s; got L=%d F=%d hidden=(%d, %d)"
                          % (MLP_MAX_LIST_LEN, MLP_MAX_LIST_LEN_NARROW, MLP_MAX_FEATURES,
                             MLP_MAX_HIDDEN, L, F, H1, H2))
-    r = prepare_relevance(relevance, X[:, :, 0])
-    nn = prepare_n(n, B)
+    dev = X.device
+    r, nn = _labels_and_n(relevance, n, B, L, dev)
     lib = _C.lib()
-    P = lib.ltr_mlp_param_count(F, H1, H2)
-    lossv = torch.empty(B, dtype=torch.float32, device=X.device)
-    flat = out if out is not None else torch.empty(P, dtype=torch.float32, device=X.device)
+    P, ws_bytes = _mlp_sizes_for(B, F, H1, H2)
+    lossv = torch.empty(B, dtype=torch.float32, device=dev)
+    flat = out if out is not None else torch.empty(P, dtype=torch.float32, device=dev)
     if flat.numel() != P or flat.dtype != torch.float32 or not flat.is_contiguous():
         raise ValueError("out must be a contiguous float32 tensor of %d elements" % P)
-    lsum = torch.zeros(1, dtype=torch.float32, device=X.device) if return_loss_sum else None
-    scores = torch.zeros(B, L, dtype=torch.float32, device=X.device) if return_scores else None
-    ws_bytes = lib.ltr_mlp_workspace_bytes(B, F, H1, H2)
-    ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=X.device)
+    # (loss_sum is written, not accumulated, by the reduction launch; B == 0 launches nothing)
+    lsum = None
+    if return_loss_sum:
+        lsum = (torch.empty if B > 0 else torch.zeros)(1, dtype=torch.float32, device=dev)
+    scores = torch.zeros(B, L, dtype=torch.float32, device=dev) if return_scores else None
     go = None if grad_out is None else grad_out.reshape(B).float().contiguous()
     with _C.device_ctx(X):
-        _C.check(lib.ltr_mlp_pairwise_f32(
-            kind, float(sigma), _C.ptr(X), *[_C.ptr(t) for t in flat_params], _C.ptr(r),
-            _C.label_dtype(r), _C.ptr(nn), _C.ptr(go), B, L, F, H1, H2, _C.ptr(lossv),
-            _C.ptr(scores), _C.ptr(flat), _C.ptr(lsum), _C.ptr(ws), ws_bytes, _C.stream_of(X)))
+        st = _C.stream_of(X)
+        ws = _mlp_workspace(dev, st, ws_bytes)
+        rc = lib.ltr_mlp_pairwise_f32(
+            kind, float(sigma), X.data_ptr(), flat_params[0].data_ptr(), flat_params[1].data_ptr(),
+            flat_params[2].data_ptr(), flat_params[3].data_ptr(), flat_params[4].data_ptr(),
+            flat_params[5].data_ptr(), r.data_ptr(), _LABEL_CODE[r.dtype], nn.data_ptr(),
+            None if go is None else go.data_ptr(), B, L, F, H1, H2, lossv.data_ptr(),
+            None if scores is None else scores.data_ptr(), flat.data_ptr(),
+            None if lsum is None else lsum.data_ptr(), ws.data_ptr(), ws_bytes, st)
+        if rc != 0:
+            _C.check(rc)
     res = (lossv, _split_grads(flat, F, H1, H2))
     if return_scores:
         res = res + (scores,)
@@ -444,7 +476,7 @@ class _MLPLossFunction(torch.autograd.Function):
         parts = list(_split_grads(flat * grad_total, *ctx.dims))
         if ctx.extra:
             parts[0] = parts[0][:, :ctx.dims[0] - ctx.extra]
-        scaled = tuple(g.reshape(s) for g, s in zip(parts, ctx.shapes))
+        scaled = tuple(g if g.shape == s else g.reshape(s) for g, s in zip(parts, ctx.shapes))
         return (None, None, None, None, None) + scaled
 
 
