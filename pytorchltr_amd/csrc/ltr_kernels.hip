@@ -880,37 +880,41 @@ __device__ __forceinline__ float pairwise_core_sym(const QueryLds &q, int nb, in
     while (u < u1) {
         const bool diag = (a == b);
         const int jend = diag ? (1 + ((a == nt - 1) ? dlast : 32)) : 64;
-        // ---- load the home tile and the visitor tile (rotated by j) of this segment ----
+        // ---- load the home tile of this segment ----
         const int hidx = 64 * a + lane;
         const bool hvalid = hidx < nb;
-        const int vidx = 64 * b + ((lane + j) & 63);
-        const bool vvalid = vidx < nb;
-        float sh, yh, Gh = 0.f, rh = 0.f, sv, yv, Gv = 0.f, rv = 0.f;
+        float sh, yh, Gh = 0.f, rh = 0.f;
         if (KIND == LTR_NDCG2) {
             const float4 hv = q.q4[hvalid ? hidx : 0];
-            const float4 vv = q.q4[vvalid ? vidx : 0];
             sh = hv.x; yh = hvalid ? hv.y : kNaN; Gh = hv.z; rh = hv.w;
-            sv = vv.x; yv = vvalid ? vv.y : kNaN; Gv = vv.z; rv = vv.w;
         } else {
             const float2 hv = q.sy[hvalid ? hidx : 0];
-            const float2 vv = q.sy[vvalid ? vidx : 0];
-            if (kRowWeight) {
-                sh = hvalid ? hv.x : kNaN; yh = hv.y;
-                sv = vvalid ? vv.x : kNaN; yv = vv.y;
-            } else {
-                sh = hv.x; yh = hvalid ? hv.y : kNaN;
-                sv = vv.x; yv = vvalid ? vv.y : kNaN;
-            }
+            if (kRowWeight) { sh = hvalid ? hv.x : kNaN; yh = hv.y; }
+            else { sh = hv.x; yh = hvalid ? hv.y : kNaN; }
         }
-        float gh = 0.f, gv = 0.f;
-        // LambdaNDCG2: the discount difference delta(|rank_home - rank_visitor|) comes from an LDS
-        // table; it is fetched ONE STEP AHEAD (the next visitor's rank is one rotation away), so the
-        // LDS round trip is off the dependency chain of the step (the pass is latency-bound)
-        float dcur = 0.f;
-        if (KIND == LTR_NDCG2) dcur = q.delta[(int)fabsf(rh - rv)];
-
+        float gh = 0.f;
+        // A visitor chain: the visitor tile rotated by `rot` lanes, its gradient accumulator travelling
+        // with it.  LambdaNDCG2: the discount difference delta(|rank_home - rank_visitor|) comes
+        // from an LDS table; it is fetched ONE STEP AHEAD (the next visitor's rank is one rotation
+        // away), so the LDS round trip is off the dependency chain of the step.
+        struct Vis { float sv, yv, Gv, rv, gv, dcur; };
+        auto load_vis = [&](Vis &V, int rot) {
+            const int vidx = 64 * b + ((lane + rot) & 63);
+            const bool vvalid = vidx < nb;
+            V.Gv = 0.f; V.rv = 0.f; V.gv = 0.f; V.dcur = 0.f;
+            if (KIND == LTR_NDCG2) {
+                const float4 vv = q.q4[vvalid ? vidx : 0];
+                V.sv = vv.x; V.yv = vvalid ? vv.y : kNaN; V.Gv = vv.z; V.rv = vv.w;
+                V.dcur = q.delta[(int)fabsf(rh - V.rv)];
+            } else {
+                const float2 vv = q.sy[vvalid ? vidx : 0];
+                if (kRowWeight) { V.sv = vvalid ? vv.x : kNaN; V.yv = vv.y; }
+                else { V.sv = vv.x; V.yv = vvalid ? vv.y : kNaN; }
+            }
+        };
         // one evaluation of the pair (home, visitor); `half`: only lanes < 32 count (j == 32)
-        auto visit = [&](bool half) {
+        auto visit = [&](Vis &V, bool half) {
+            const float sv = V.sv, yv = V.yv;
             const bool on = half ? (lane < 32) : true;
             float c;                                             // d term / d s_home
             if (KIND == LTR_HINGE || KIND == LTR_DCG_HINGE) {
@@ -929,7 +933,7 @@ __device__ __forceinline__ float pairwise_core_sym(const QueryLds &q, int nb, in
                 const bool gt = yh > yv, lt = yh < yv;
                 float Wp = 1.0f;
                 if (KIND == LTR_ARP2) Wp = fabsf(yh - yv);
-                if (KIND == LTR_NDCG2) Wp = dcur * fabsf(Gh - Gv);
+                if (KIND == LTR_NDCG2) Wp = V.dcur * fabsf(Gh - V.Gv);
                 const float t = (sh - sv) * c1;
                 const float z = gt ? t : -t;
                 const float e = __builtin_amdgcn_exp2f(-fabsf(z));
@@ -951,32 +955,42 @@ __device__ __forceinline__ float pairwise_core_sym(const QueryLds &q, int nb, in
                 c = ok ? (yv - (yh + yv) * sneg) : 0.0f;
             }
             gh += c;
-            gv -= c;
+            V.gv -= c;
         };
-        auto rotate = [&]() {
-            sv = wave_rol1(sv); yv = wave_rol1(yv); gv = wave_rol1(gv);
-            if (KIND == LTR_NDCG2) { Gv = wave_rol1(Gv); rv = wave_rol1(rv); }
+        auto rotate = [&](Vis &V) {
+            V.sv = wave_rol1(V.sv); V.yv = wave_rol1(V.yv); V.gv = wave_rol1(V.gv);
+            if (KIND == LTR_NDCG2) { V.Gv = wave_rol1(V.Gv); V.rv = wave_rol1(V.rv); }
+        };
+        // a full step of a chain (the discount of the NEXT step requested first)
+        auto step = [&](Vis &V) {
+            float dnext = 0.f;
+            if (KIND == LTR_NDCG2) dnext = q.delta[(int)fabsf(rh - wave_rol1(V.rv))];
+            visit(V, false);
+            rotate(V);
+            V.dcur = dnext;
+        };
+        auto flush_vis = [&](const Vis &V, int rot) {
+            const int fidx = 64 * b + ((lane + rot) & 63);       // the visitor now in this lane
+            if (fidx < nb) gw[fidx] += V.gv;
         };
 
         const int steps = min(jend - j, u1 - u);
         u += steps;
         const int jstop = j + steps;
-        // full steps (every lane), then at most one half step (diagonal job, j == 32)
-        const int jfull = diag ? min(jstop, 32) : jstop;
-        for (; j < jfull; ++j) {
-            float dnext = 0.f;
-            if (KIND == LTR_NDCG2) dnext = q.delta[(int)fabsf(rh - wave_rol1(rv))];
-            visit(false);
-            rotate();
-            dcur = dnext;
-        }
-        if (j < jstop) { visit(true); rotate(); ++j; }
-
-        // ---- flush both accumulators into this wave's private slice ----
-        if (hvalid) gw[hidx] += gh;
+        // full steps (every lane), then at most one half step (diagonal job, j == 32): the LAST step
+        const bool has_half = diag && jstop == 33;
+        // (Two visitor chains per lane -- the steps [j, j+n/2) and [j+n/2, jstop) interleaved, two
+        // independent dependency chains -- were measured and dropped: correct, but 2-10 % slower in
+        // every kernel (C2 fused hinge 10.5 -> 11.2 us, LambdaNDCG2 16.2 -> 16.6, 256 x 1000 hinge
+        // loss 49.7 -> 56.2): the second chain's registers and moves cost more than its ILP buys.)
         {
-            const int fidx = 64 * b + ((lane + j) & 63);         // the visitor now in this lane
-            if (fidx < nb) gw[fidx] += gv;
+            Vis A;
+            load_vis(A, j);
+            const int jfull = has_half ? 32 : jstop;
+            for (; j < jfull; ++j) step(A);
+            if (has_half) { visit(A, true); rotate(A); ++j; }
+            if (hvalid) gw[hidx] += gh;
+            flush_vis(A, j);
         }
         if (j == jend) {
             if (++b == nt) { ++a; b = a; }
