@@ -357,6 +357,9 @@ def _mlp_sizes_for(B, F, H1, H2):
 def _mlp_workspace(dev, stream, ws_bytes):
     """The per-workgroup partial vectors (15 MB at the guide's network) live only between the two
     launches of one call, which run in stream order: one buffer per (device, stream) is reused."""
+    if torch.cuda.is_current_stream_capturing():
+        # a buffer allocated under capture belongs to the graph's pool: never cache it
+        return torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=dev)
     key = (dev.index, stream, ws_bytes)
     ws = _mlp_workspaces.get(key)
     if ws is None:
