@@ -187,3 +187,26 @@ def test_fused_plan_for_the_baseline_shapes():
     assert lib.ltr_linear_fused_plan(99, 8, 100, 136) == _C.PLAN_NONE
     # the cluster kernel's scratch rides behind the (F+1, B) partials
     assert lib.ltr_linear_workspace_bytes(256, 1000, 220) > lib.ltr_linear_workspace_bytes(256, 128, 220)
+
+
+def test_mlp_shape_limits_are_host_logic():
+    """Which shapes the fused MLP step takes is decided on the host (no launch): lists up to 256
+    documents while the feature rows fit the tile kernel (F <= 144), 128 for wider rows; the Python
+    mirror (fused.mlp_supported) agrees with the library (ltr_mlp_max_list_len)."""
+    from pytorchltr_amd import _C, fused
+    lib = _C.lib()
+    for F in (4, 48, 136, 144, 148, 200, 224):
+        assert lib.ltr_mlp_max_list_len(F) == fused.mlp_max_list_len(F) == (256 if F <= 144 else 128)
+    assert lib.ltr_mlp_max_list_len(6) == 0 and lib.ltr_mlp_max_list_len(228) == 0
+    assert fused.mlp_supported(256, 136, 50, 10) and not fused.mlp_supported(257, 136, 50, 10)
+    assert fused.mlp_supported(128, 220, 64, 16) and not fused.mlp_supported(129, 220, 64, 16)
+    assert not fused.mlp_supported(64, 136, 65, 10) and not fused.mlp_supported(64, 138, 50, 10)
+    # the workspace covers the larger of the two kernel grids, rows padded to 16 bytes
+    P = lib.ltr_mlp_param_count(136, 50, 10)
+    assert P == 50 * 136 + 50 + 10 * 50 + 10 + 10 + 1
+    assert lib.ltr_mlp_workspace_bytes(3, 136, 50, 10) == 3 * ((P + 3) // 4 * 4) * 4
+    z = 8
+    assert lib.ltr_mlp_pairwise_f32(0, 1.0, z, z, z, z, z, z, z, z, 0, z, None, 1, 16, 8, 4, 4, z, None,
+                                    z, None, z, 4, None) == -5              # LTR_ERR_WORKSPACE
+    assert lib.ltr_mlp_scores_f32(z, z, z, z, z, z, z, z, 1, 257, 8, 4, 4, z, None) == -4
+    assert lib.ltr_mlp_scores_f32(z, z, z, z, z, z, z, z, 1, 129, 200, 4, 4, z, None) == -4
