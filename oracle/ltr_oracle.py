@@ -47,7 +47,8 @@ def build(force=False):
 def _load():
     global _lib
     if _lib is None:
-        _lib = ctypes.CDLL(build())
+        # LTR_ORACLE_LIB: another build of ltr_oracle.c (the sanitizer build of scripts/sanitize_host.sh)
+        _lib = ctypes.CDLL(os.environ.get("LTR_ORACLE_LIB") or build())
     return _lib
 
 

@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libltr_io.so")
+# LTR_IO_LIB: another build of the same library (e.g. the sanitizer build of scripts/sanitize_host.sh)
+LIB_PATH = os.environ.get("LTR_IO_LIB") or os.path.join(_HERE, "csrc", "libltr_io.so")
 
 OK, FILE_ERROR, FORMAT_ERROR, MEMORY_ERROR, ARG_ERROR = range(5)
 

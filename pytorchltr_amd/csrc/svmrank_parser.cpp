@@ -257,6 +257,7 @@ int ltr_svmrank_read(void *handle, double *xs, float *xs_f32, int32_t *ys, int64
     run_parallel(nt, [&](int t) {
         const Chunk &c = ps->chunks[(size_t)t];
         const size_t r0 = ps->row_base[(size_t)t];
+        if (c.ys.empty()) return;                        // (a chunk without rows: its vectors' data() may be null)
         if (xs) memset(xs + r0 * cols, 0, sizeof(double) * c.ys.size() * cols);
         if (xs_f32) memset(xs_f32 + r0 * cols, 0, sizeof(float) * c.ys.size() * cols);
         if (ys) memcpy(ys + r0, c.ys.data(), sizeof(int32_t) * c.ys.size());
