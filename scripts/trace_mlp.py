@@ -22,7 +22,7 @@ PHASES = ["weights->LDS", "labels", "layer1 MFMA", "layers 2,3 + barrier", "pair
 PHASES_TILE = ["rest of prologue", "(fwd) next fill issue + barrier", "layer-1 tile + L2 partial", "owner: layers 2,3",
                "pair pass", "bwd: refill + dH2 rows", "bwd GEMMs (dW2, dH1, dW1)", "partial vector",
                "(prologue) fragment loads", "(prologue) scheduling", "(fwd) owner + parking of fill before",
-               "(fwd) wait for P + image write"]
+               "(fwd) wait for P + image write", "(tuning) scheduling, second run"]
 
 
 def main():
