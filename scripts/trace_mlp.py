@@ -22,7 +22,7 @@ PHASES = ["weights->LDS", "labels", "layer1 MFMA", "layers 2,3 + barrier", "pair
 PHASES_TILE = ["rest of prologue", "(fwd) next fill issue + barrier", "layer-1 tile + L2 partial", "owner: layers 2,3",
                "pair pass", "bwd: refill + dH2 rows", "bwd GEMMs (dW2, dH1, dW1)", "partial vector",
                "(prologue) fragment loads", "(prologue) scheduling", "(fwd) owner + parking of fill before",
-               "(fwd) wait for P + image write", "(tuning) scheduling, second run"]
+               "(fwd) wait for P + image write", "(tuning) scheduling, second run", "(fwd) owner rows", "(fwd) parking"]
 
 
 def main():
@@ -64,7 +64,7 @@ def main():
     t = trace.view(grid, 16).double().cpu()
     t = t[t.sum(1) > 0]                      # (the workspace is sized for the larger grid)
     grid = t.shape[0]
-    tot = t[:, :14].sum(1)
+    tot = t[:, :12].sum(1) + t[:, 13:15].sum(1)
     print("workgroups %d, queries/workgroup %.1f; total cycles/workgroup mean %.0f max %.0f" % (
         grid, B / grid, tot.mean(), tot.max()))
     for i, name in enumerate(PHASES_TILE if args.layout == "tile" else PHASES):
