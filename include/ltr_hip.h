@@ -84,7 +84,9 @@ int ltr_device_status(int clear);
 /* Tests only: != 0 makes every in-launch wait of the cluster kernel give up at once. */
 void ltr_debug_force_timeout(int on);
 /* Tests / measurements only: which kernel layout ltr_mlp_pairwise_f32 takes where both apply.
- * 0 = default (4-wave tile kernel, csrc/ltr_mlp2.inc), 1 = the 8-wave kernel of csrc/ltr_mlp.inc.
+ * 0 = automatic (the 4-wave tile kernel of csrc/ltr_mlp2.inc for batches of at least two queries per
+ * CU-slot and for lists over 128 documents, else the 8-wave kernel of csrc/ltr_mlp.inc), 1 = the
+ * 8-wave kernel wherever it applies, 2 = the tile kernel wherever it applies.
  * LTR_MLP_LAYOUT in the environment sets the initial value. */
 void ltr_debug_mlp_layout(int layout);
 

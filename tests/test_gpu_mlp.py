@@ -23,7 +23,7 @@ def _mlp_layout(request):
     kernel (csrc/ltr_mlp2.inc, the default for F <= 144) and the 8-wave kernel (csrc/ltr_mlp.inc,
     which also serves wider feature rows and the forward-only scores)."""
     from pytorchltr_amd import _C
-    _C.lib().ltr_debug_mlp_layout(1 if request.param == "wide" else 0)
+    _C.lib().ltr_debug_mlp_layout(1 if request.param == "wide" else 2)
     yield
     _C.lib().ltr_debug_mlp_layout(0)
 
