@@ -11,8 +11,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libltr_hip.so")
-SOURCES = [os.path.join(CSRC, "ltr_kernels.hip")]
-# every .inc the translation unit includes, and the public header
+# three translation units, compiled side by side and linked into one library: the loss / metric /
+# helper kernels with the C ABI, the fused Linear scorer + loss kernels, the fused MLP + scorer layer
+SOURCES = [os.path.join(CSRC, f) for f in ("ltr_kernels.hip", "ltr_linear.hip", "ltr_mlp.hip")]
+OBJ_DIR = os.path.join(_ROOT, "build", "obj")
+# every .inc the translation units include, and the public header
 DEPENDS = SOURCES + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".inc")) + \
     [os.path.join(_ROOT, "include", "ltr_hip.h")]
 ARCH = "gfx950"
@@ -35,18 +38,32 @@ def is_stale():
     return any(os.path.getmtime(d) > built for d in DEPENDS)
 
 
-def build_extension(force=False, verbose=False):
+def build_extension(force=False, verbose=False, extra_flags=(), lib_path=None):
     """Compile every HIP source into libltr_hip.so for gfx950.  Returns the .so path."""
-    if not force and not is_stale():
+    lib_path = lib_path or LIB_PATH
+    if not force and lib_path == LIB_PATH and not is_stale():
         return LIB_PATH
-    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
-           "-I", os.path.join(_ROOT, "include"), "-I", CSRC,
-           "-o", LIB_PATH] + SOURCES
+    obj_dir = OBJ_DIR if lib_path == LIB_PATH else lib_path + ".obj"
+    os.makedirs(obj_dir, exist_ok=True)
+    common = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
+              "-Wall", "-Wno-unused-function", "-I", os.path.join(_ROOT, "include"), "-I", CSRC] + list(extra_flags)
+    jobs = []
+    for src in SOURCES:
+        obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
+        cmd = common + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        jobs.append((cmd, subprocess.Popen(cmd), obj))
+    objs = []
+    for cmd, proc, obj in jobs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+        objs.append(obj)
+    link = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc", "-o", lib_path] + objs
     if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    return LIB_PATH
+        print(" ".join(link), flush=True)
+    subprocess.check_call(link)
+    return lib_path
 
 
 def build_io(force=False, verbose=False):

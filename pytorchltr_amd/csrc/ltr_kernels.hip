@@ -16,1017 +16,60 @@
 //   * per-query reductions: DPP/shuffle wave reduction + one LDS hop across waves.
 //
 // Written for gfx950 only: wave size 64 is hard-coded.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include <mutex>
 
-#include "ltr_hip.h"
+#include "ltr_common.inc"
 
 namespace {
 
-constexpr int kWave = 64;
-constexpr int kMaxListLen = 4096;
-constexpr int kSymMaxLen = 1024;   // longest list the symmetric pair pass takes (LDS: one slice per wave)
-constexpr float kLog2e = 1.4426950408889634f;
-constexpr float kLn2 = 0.6931471805599453f;
-
-// ---------------------------------------------------------------------------------
-// Device status word.  The only kernels that can fail at run time are the ones whose workgroups
-// wait for each other (ltr_cluster.inc): a wait that gives up must not end as a silent NaN.  One
-// pinned, device-mapped host page per process holds a sticky status word; a kernel that gives up
-// stores LTR_ERR_TIMEOUT there (system-scope store, rare path), and the linear-scorer entry
-// points return it -- without any synchronisation: a host read of pinned memory -- on the NEXT
-// call; ltr_device_status() reads / clears it explicitly.  Allocated lazily outside stream capture;
-// until then (or when the allocation fails) the kernels only poison their outputs with NaN.
-// ---------------------------------------------------------------------------------
-// Every launcher reports its launch with hipGetLastError(), which returns (and clears) the LAST error
-// of the calling thread -- including one an unrelated earlier call left behind.  The entry points
-// therefore drop stale state first, so that a non-zero return is about THIS call.
-#define LTR_CLEAR_STALE_ERROR() ((void)hipGetLastError())
-
-struct StatusPage { int *host; int *dev; };
-inline StatusPage &status_page_ref() { static StatusPage sp = {nullptr, nullptr}; return sp; }
-inline int *status_device_ptr(hipStream_t stream)
+// The device status page (see ltr_common.inc): ONE pinned, device-mapped host page per process, created
+// under a mutex on the first multi-workgroup launch outside stream capture (two host threads may make
+// their first launch concurrently); its device-side address is looked up once per device.
+struct StatusPage { int *host; int *dev[kMaxDevices]; bool tried; };
+inline StatusPage &status_page_ref() { static StatusPage sp = {}; return sp; }
+inline std::mutex &status_mutex() { static std::mutex m; return m; }
+inline int *status_device_ptr_impl(hipStream_t stream)
 {
     StatusPage &sp = status_page_ref();
-    if (sp.dev) return sp.dev;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= kMaxDevices) return nullptr;
+    if (int *d = __atomic_load_n(&sp.dev[dev], __ATOMIC_ACQUIRE)) return d;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
         (void)hipGetLastError();
         return nullptr;
     }
-    static bool tried = false;
-    if (tried) return nullptr;
-    tried = true;
-    void *h = nullptr, *d = nullptr;
-    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    for (int i = 0; i < 16; ++i) reinterpret_cast<volatile int *>(h)[i] = 0;
-    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return nullptr; }
-    sp.host = reinterpret_cast<int *>(h);
-    sp.dev = reinterpret_cast<int *>(d);
-    return sp.dev;
-}
-inline int status_peek()
-{
-    const StatusPage &sp = status_page_ref();
-    return sp.host ? *reinterpret_cast<volatile int *>(sp.host) : 0;
-}
-
-// ---------------------------------------------------------------------------------
-// small device helpers
-// ---------------------------------------------------------------------------------
-__device__ __forceinline__ float load_label(const void *rel, int dtype, size_t idx)
-{
-    // wave-uniform switch; int64 -> fp32 narrowing happens in registers (no cast kernel)
-    if (dtype == LTR_LABEL_I64) return (float)((const int64_t *)rel)[idx];
-    if (dtype == LTR_LABEL_F32) return ((const float *)rel)[idx];
-    return (float)((const int32_t *)rel)[idx];
-}
-
-// Stage one query's (score, label) pairs into LDS.  The label-dtype switch is hoisted out of
-// the loop (wave-uniform), int64 -> fp32 narrowing happens in registers (no cast kernel).
-template <typename LabelT>
-__device__ __forceinline__ void stage_rows_t(float2 *sy, const float *__restrict__ srow,
-                                             const LabelT *__restrict__ yrow, int L, int nb,
-                                             int tid, int T)
-{
-    for (int m = tid; m < L; m += T) {
-        const float sv = srow[m];
-        const float yv = (float)yrow[m];
-        if (m < nb) sy[m] = make_float2(sv, yv);
+    std::lock_guard<std::mutex> lock(status_mutex());
+    if (sp.dev[dev]) return sp.dev[dev];
+    if (!sp.host) {
+        if (sp.tried) return nullptr;
+        sp.tried = true;
+        void *h = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        for (int i = 0; i < 16; ++i) reinterpret_cast<volatile int *>(h)[i] = 0;
+        __atomic_store_n(&sp.host, reinterpret_cast<int *>(h), __ATOMIC_RELEASE);
     }
+    void *d = nullptr;
+    if (hipHostGetDevicePointer(&d, sp.host, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    __atomic_store_n(&sp.dev[dev], reinterpret_cast<int *>(d), __ATOMIC_RELEASE);
+    return sp.dev[dev];
 }
-
-__device__ __forceinline__ void stage_rows(float2 *sy, const float *srow, const void *rel,
-                                           int dtype, size_t row, int L, int nb, int tid, int T)
+inline int status_peek_impl()
 {
-    if (dtype == LTR_LABEL_I64)
-        stage_rows_t(sy, srow, (const int64_t *)rel + row, L, nb, tid, T);
-    else if (dtype == LTR_LABEL_F32)
-        stage_rows_t(sy, srow, (const float *)rel + row, L, nb, tid, T);
-    else
-        stage_rows_t(sy, srow, (const int32_t *)rel + row, L, nb, tid, T);
+    int *h = __atomic_load_n(&status_page_ref().host, __ATOMIC_ACQUIRE);
+    return h ? *reinterpret_cast<volatile int *>(h) : 0;
 }
 
-// Labels only (the fused scorer kernels compute the scores themselves).
-template <typename LabelT>
-__device__ __forceinline__ void stage_labels_t(float2 *sy, const LabelT *__restrict__ yrow, int L,
-                                               int nb, int tid, int T)
+}  // namespace
+
+extern "C" __attribute__((visibility("hidden"))) int *ltr_internal_status_device_ptr(void *stream)
 {
-    for (int m = tid; m < L; m += T) {
-        const float yv = (float)yrow[m];
-        if (m < nb) sy[m].y = yv;
-    }
+    return status_device_ptr_impl((hipStream_t)stream);
 }
+extern "C" __attribute__((visibility("hidden"))) int ltr_internal_status_peek(void) { return status_peek_impl(); }
 
-__device__ __forceinline__ void stage_labels(float2 *sy, const void *rel, int dtype, size_t row,
-                                             int L, int nb, int tid, int T)
-{
-    if (dtype == LTR_LABEL_I64) stage_labels_t(sy, (const int64_t *)rel + row, L, nb, tid, T);
-    else if (dtype == LTR_LABEL_F32) stage_labels_t(sy, (const float *)rel + row, L, nb, tid, T);
-    else stage_labels_t(sy, (const int32_t *)rel + row, L, nb, tid, T);
-}
-
-__device__ __forceinline__ int clamp_n(int64_t n, int L)
-{
-    return n < 0 ? 0 : (n > (int64_t)L ? L : (int)n);
-}
-
-// Which query a workgroup takes (one workgroup per query: the fused scorer+loss kernels and the
-// loss kernel).  The hardware starts block ids in
-// order, round-robin over the 8 XCDs and, inside an XCD, over its 32 CUs (a CU hosts ids i, i+256,
-// i+512, ...), and a launch of a few workgroups per CU lasts as long as its most loaded CU / its
-// last workgroup.  Measured at C2/C3 shapes (n ~ U[1,128], B = 1024; profiles/README.md): batch in
-// random order 13.5-14.0 us (hinge) / 23.7 (LambdaNDCG2) / 18.2 (logistic); the same batch sorted
-// by n descending 12.2 / 20.0 / 15.3 -- long lists first, and every CU gets one list of each
-// quartile.  A full sort of n[] inside every workgroup costs more than that (tried: counting
-// sort, 8 000-15 000 cycles), so the order is approximated with 64-query samples: the batch is cut
-// into G = ceil(B/64) interleaved groups (group g = chunks of 8 consecutive ids, G chunks apart),
-// each group is ranked by n descending, and block id `pos` -- member number m of its group -- takes
-// the group's m-th longest list.  Early ids get every group's longest lists, late ids the shortest:
-// 12.1 / 20.3 / 15.5 us with the permutation applied on the host.  ONE wave finds the query
-// without LDS traffic: one n per lane (8 x 64-byte segments), a radix select over the bits of n
-// with ballots (uniform control flow, ~100 instructions), ties by lane order.  A bijection inside
-// each group and a pure function of n[]; every output is indexed by the query, so results do not
-// depend on it.
-#ifndef LTR_SCHED_MAX_PER_CU
-#define LTR_SCHED_MAX_PER_CU 4        // register-tile kernel (B = 8 x #CUs: 22.1 -> 23.9 us with it)
-#endif
-#ifndef LTR_LOSS_SCHED_MAX_PER_CU
-#define LTR_LOSS_SCHED_MAX_PER_CU 16   // loss kernel, general fused kernel
-#endif
-__device__ __forceinline__ int sched_query_sampled(const int64_t *__restrict__ n, int B, int L, int G, int tid,
-                                                   int &nb_out, int pos)
-{
-    __shared__ int s_sel[2];
-    if (tid < 64) {
-        const int lane = tid;
-        const int u = pos >> 3;
-        const int jp = u / G;
-        const int gam = u - jp * G;
-        int rho = jp * 8 + (pos & 7);                            // this block's member number
-        const int id = ((lane >> 3) * G + gam) * 8 + (lane & 7); // member `lane` of the group
-        unsigned long long cand = __ballot(id < B);              // a prefix of the lanes (ids grow with lane)
-        const int key = clamp_n(n[min(id, B - 1)], L);
-        // (all lists equally long, e.g. full lists: cand stays the whole group and rho the lane)
-        const bool flat = __ballot(key != __builtin_amdgcn_readfirstlane(key)) == 0ull;
-        // (LTR_SCHED_LOW_BITS low bits of n are ignored: an approximate order balances as well and
-        // every bit is one more dependent ballot round in front of the first load)
-#ifndef LTR_SCHED_LOW_BITS
-#define LTR_SCHED_LOW_BITS 3
-#endif
-        for (int bt = flat ? -1 : 31 - __builtin_clz(L); bt >= LTR_SCHED_LOW_BITS; --bt) {   // descending n: set bits first
-            const unsigned long long m = __ballot(((key >> bt) & 1) != 0) & cand;
-            const int c = __popcll(m);
-            if (rho < c) cand = m;
-            else { rho -= c; cand &= ~m; }
-        }
-        // cand = the lanes holding the selected n; the rho-th of them in lane order takes the block
-        const int below = __popcll(cand & ((1ull << lane) - 1ull));
-        if ((((cand >> lane) & 1ull) != 0ull) && below == rho) { s_sel[0] = id; s_sel[1] = key; }
-    }
-    __syncthreads();
-    nb_out = __builtin_amdgcn_readfirstlane(s_sel[1]);           // saves the dependent n[b] load
-    return __builtin_amdgcn_readfirstlane(s_sel[0]);
-}
-
-// Cross-lane adds on the DPP path (no LDS round trip; HIP's __shfl_* lower to ds_bpermute).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_move(float v)
-{
-    // lanes outside ROW_MASK (or without a valid source) receive 0
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
-}
-
-// Sum over the 4 lanes of a quad; every lane of the quad gets the result.
-__device__ __forceinline__ float quad_sum(float v)
-{
-    v += dpp_move<0xB1, 0xF>(v);      // quad_perm [1,0,3,2]
-    v += dpp_move<0x4E, 0xF>(v);      // quad_perm [2,3,0,1]
-    return v;
-}
-
-// Sum over the 64 lanes of the wave; every lane gets the result (DPP row ops + one readlane).
-__device__ __forceinline__ float wave_sum(float v)
-{
-    v = quad_sum(v);
-    v += dpp_move<0x141, 0xF>(v);     // row_half_mirror: 8-lane sums
-    v += dpp_move<0x140, 0xF>(v);     // row_mirror: every lane holds its 16-lane row sum
-    v += dpp_move<0x142, 0xA>(v);     // row_bcast15 -> rows 1 and 3 add the previous row
-    v += dpp_move<0x143, 0xC>(v);     // row_bcast31 -> rows 2 and 3 add rows 0+1: lane 63 = total
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-
-// Sum over the whole workgroup; every thread gets the result.  Deterministic order.
-// `red` is an LDS scratch of >= 16 floats.  Contains barriers: call from uniform code.
-__device__ __forceinline__ float block_sum(float v, float *red)
-{
-    v = wave_sum(v);
-    const int nw = blockDim.x >> 6;
-    if (nw == 1) return v;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float t = 0.f;
-    for (int i = 0; i < nw; ++i) t += red[i];
-    return t;
-}
-
-// Two sums in one pass (same barriers): used for (loss, sum of gradients).
-__device__ __forceinline__ void block_sum2(float &a, float &b, float *red)
-{
-    a = wave_sum(a);
-    b = wave_sum(b);
-    const int nw = blockDim.x >> 6;
-    if (nw == 1) return;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = a; red[2 * (threadIdx.x >> 6) + 1] = b; }
-    __syncthreads();
-    float ta = 0.f, tb = 0.f;
-    for (int i = 0; i < nw; ++i) { ta += red[2 * i]; tb += red[2 * i + 1]; }
-    a = ta;
-    b = tb;
-}
-
-// log2(1 + e) for e in [0, 1]; two-term series below 2^-10 where 1+e would round e away.
-__device__ __forceinline__ float log2_1p(float e)
-{
-    const float direct = __builtin_amdgcn_logf(1.0f + e);      // v_log_f32 == log2
-    const float series = e * (1.0f - 0.5f * e) * kLog2e;
-    return e < 0.0009765625f ? series : direct;
-}
-
-// ---------------------------------------------------------------------------------
-// counting rank: for every owned document k < nb,
-//   rank_s[k] = #{m < nb : s_m > s_k or (s_m == s_k and m < k)}     (score, descending)
-//   rank_y[k] = the same on labels (only if WITH_Y)
-// This is rank_by_score (utils/tensor_operations.py:48-64) restricted to the real
-// documents; padded documents rank at their own index (key -inf, index tie-break).
-// rank arrays must be zeroed by the caller when msplit > 1 (partial counts are added).
-// ---------------------------------------------------------------------------------
-template <int DPT, bool WITH_Y>
-__device__ __forceinline__ void count_ranks(const float2 *sy, int nb, int owners, int o,
-                                            int m0, int m1, bool partial, int *rank_s,
-                                            int *rank_y)
-{
-    for (int base = 0; base < nb; base += owners * DPT) {
-        const int wave_first = base + (o & ~63);
-        if (wave_first >= nb) continue;                       // wave-uniform
-        float sk[DPT], yk[DPT];
-        int cs[DPT], cy[DPT], kk[DPT];
-#pragma unroll
-        for (int c = 0; c < DPT; ++c) {
-            kk[c] = base + o + c * owners;
-            const bool valid = kk[c] < nb;
-            const float2 v = valid ? sy[kk[c]] : make_float2(0.f, 0.f);
-            sk[c] = v.x; yk[c] = v.y; cs[c] = 0; cy[c] = 0;
-        }
-#pragma unroll 4
-        for (int m = m0; m < m1; ++m) {
-            const float2 v = sy[m];
-#pragma unroll
-            for (int c = 0; c < DPT; ++c) {
-                const bool before = m < kk[c];
-                cs[c] += (v.x > sk[c]) | ((v.x == sk[c]) & before);
-                if (WITH_Y) cy[c] += (v.y > yk[c]) | ((v.y == yk[c]) & before);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < DPT; ++c) {
-            if (kk[c] < nb) {
-                if (partial) {
-                    atomicAdd(&rank_s[kk[c]], cs[c]);
-                    if (WITH_Y) atomicAdd(&rank_y[kk[c]], cy[c]);
-                } else {
-                    rank_s[kk[c]] = cs[c];
-                    if (WITH_Y) rank_y[kk[c]] = cy[c];
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// pair terms.  Conventions: owner document k (registers), streamed document m (LDS).
-//   c1 = sigma * log2(e)   so that exp(-sigma*d) = exp2(-c1*d)
-// Gradient accumulators are in units of sigma/ln2 (applied once per document at the end).
-// ---------------------------------------------------------------------------------
-
-// Hinge (loss/pairwise_additive.py:107-113): term(i,j) = max(0, 1-(s_i-s_j)) if y_i > y_j.
-// The reference zeroes `loss < 0` (strict), so at exactly the margin the gradient flows.
-__device__ __forceinline__ void pair_hinge(float sk, float yk, float sm, float ym, float &g,
-                                           float &l)
-{
-    const float d = sk - sm;
-    const bool gt = yk > ym, lt = yk < ym;
-    const float u = gt ? (1.0f - d) : (1.0f + d);
-    const bool act = (gt | lt) & (u >= 0.0f);
-    l += (gt & act) ? u : 0.0f;
-    g += act ? (gt ? -1.0f : 1.0f) : 0.0f;
-}
-
-// Logistic / ARP2 / NDCG2: term(i,j) = W_ij * log2(1 + exp(-sigma (s_i - s_j))) if y_i > y_j
-// (loss/pairwise_additive.py:158-163, loss/pairwise_lambda.py:135-140, :198-218), W symmetric.
-// Stable for any finite input (the reference overflows beyond |sigma d| ~ 88).
-__device__ __forceinline__ void pair_oriented(float sk, float yk, float sm, float ym, float W,
-                                              float c1, float &g, float &l)
-{
-    const bool gt = yk > ym, lt = yk < ym;
-    const float t = (sk - sm) * c1;
-    const float z = gt ? t : -t;                       // log2e * sigma * (s_winner - s_loser)
-    const float e = __builtin_amdgcn_exp2f(-fabsf(z));
-    const float r = __builtin_amdgcn_rcpf(1.0f + e);
-    const float psi = (z >= 0.0f) ? e * r : r;         // sigmoid(-sigma (s_win - s_lose))
-    const float lg = log2_1p(e) + fmaxf(-z, 0.0f);     // log2(1 + exp(-sigma (s_win - s_lose)))
-    const float Wm = (gt | lt) ? W : 0.0f;
-    l += gt ? Wm * lg : 0.0f;
-    g += (gt ? -Wm : Wm) * psi;
-}
-
-// ARP1 / NDCG1: term(i,j) = a_i * log2(1 + exp(-sigma (s_i - s_j))) for ALL i, j < n
-// (-log2(sigmoid ** a_i), loss/pairwise_lambda.py:114-117, :165-173).
-__device__ __forceinline__ void pair_rowweight(float sk, float ak, float sm, float am, float c1,
-                                               float &g, float &l)
-{
-    const float t = (sk - sm) * c1;
-    const float e = __builtin_amdgcn_exp2f(-fabsf(t));
-    const float r = __builtin_amdgcn_rcpf(1.0f + e);
-    const float sneg = (t >= 0.0f) ? e * r : r;        // sigmoid(-sigma (s_k - s_m))
-    const float lg = log2_1p(e) + fmaxf(-t, 0.0f);
-    l += ak * lg;
-    g += am - (ak + am) * sneg;                        // -a_k sig(-x) + a_m sig(x)
-}
-
-// lists longer than this take the sort path (DPT == 0 instantiation of metric_kernel)
-#ifndef LTR_SORT_RANK_MIN
-#define LTR_SORT_RANK_MIN 256
-#endif
-constexpr int kSortRankMinLen = LTR_SORT_RANK_MIN;
-__host__ __device__ inline int sort_pow2(int L)
-{
-    int P = 64;
-    while (P < L) P <<= 1;
-    return P;
-}
-
-// ---------------------------------------------------------------------------------
-// Ranks of long lists by a bitonic sort instead of the O(n^2) counting rank.
-// Every document becomes one 64-bit key: (order-reversed score bits << 32) | index, so that an
-// ascending unsigned sort is exactly "score descending, index ascending" -- the tie rule of the
-// counting rank (-0.0 is folded into +0.0 first so that it ties with it, as the float compare
-// does).  Slots past n hold the all-ones sentinel and stay at the tail.  Element i = e*T + tid
-// lives in register e of thread tid; a compare-exchange partner at distance j is in the same
-// thread (j >= T), reached through LDS (64 <= j < T, one buffer, two barriers), or a lane
-// shuffle (j < 64).  P = E*T is a power of two >= n.  O(P log^2 P) work: L = 1000 ranks in
-// ~1/7 of the counting rank's time on MI355X.  NaN scores sort first (the counting rank gave
-// them colliding ranks).
-// ---------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long rank_key(float v, int idx)
-{
-    const unsigned bits = __float_as_uint(v + 0.0f);
-    const unsigned asc = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
-    return ((unsigned long long)(~asc) << 32) | (unsigned)idx;
-}
-
-// inv (LDS, may be null): the low key word is a tie priority, inv[priority] = document index.
-template <int E>
-__device__ __forceinline__ void sort_ranks(unsigned long long (&v)[E], int P, int nb, int *rank_out,
-                                           unsigned long long *xbuf, const int *inv = nullptr)
-{
-    const int tid = threadIdx.x;
-    const int T = blockDim.x;
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j >= T) {
-                const int je = j / T;                          // partner register
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    if ((e & je) == 0 && (e | je) < E) {
-                        const int i = e * T + tid;
-                        const bool up = (i & k) == 0;
-                        const unsigned long long a = v[e], b = v[e | je];
-                        const bool swap = (a > b) == up;
-                        v[e] = swap ? b : a;
-                        v[e | je] = swap ? a : b;
-                    }
-                }
-            } else {
-                unsigned long long other[E];
-                if (j >= 64) {
-                    __syncthreads();                           // previous readers of xbuf are done
-#pragma unroll
-                    for (int e = 0; e < E; ++e) xbuf[e * T + tid] = v[e];
-                    __syncthreads();
-#pragma unroll
-                    for (int e = 0; e < E; ++e) other[e] = xbuf[(e * T + tid) ^ j];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v[e], j);
-                        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v[e] >> 32), j);
-                        other[e] = ((unsigned long long)hi << 32) | lo;
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const int i = e * T + tid;
-                    const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
-                    const bool smaller = v[e] < other[e];
-                    v[e] = (smaller == keep_min) ? v[e] : other[e];
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        if (v[e] != ~0ull) {
-            const int low = (int)(unsigned)v[e];
-            const int idx = inv ? inv[low] : low;
-            if (idx < nb) rank_out[idx] = e * T + tid;
-        }
-    }
-}
-
-// Counting rank on packed keys: with (order-reversed value bits << 32 | index) keys (rank_key) the
-// tie rule is part of the key, so "m comes before k" is ONE unsigned 64-bit compare and the count
-// one add-with-carry -- about 2.5x fewer VALU instructions per pair than comparing floats and
-// indices separately.  keys[k] = (score key, label key), built by the caller for k < nb.
-template <int DPT, bool WITH_Y>
-__device__ __forceinline__ void count_ranks_keyed(const ulonglong2 *keys, int nb, int owners, int o,
-                                                  int m0, int m1, bool partial, int *rank_s,
-                                                  int *rank_y)
-{
-    for (int base = 0; base < nb; base += owners * DPT) {
-        const int wave_first = base + (o & ~63);
-        if (wave_first >= nb) continue;                       // wave-uniform
-        unsigned long long kx[DPT], ky[DPT];
-        int cs[DPT], cy[DPT], kk[DPT];
-#pragma unroll
-        for (int c = 0; c < DPT; ++c) {
-            kk[c] = base + o + c * owners;
-            const ulonglong2 v = keys[kk[c] < nb ? kk[c] : 0];
-            kx[c] = v.x; ky[c] = v.y; cs[c] = 0; cy[c] = 0;
-        }
-#pragma unroll 4
-        for (int m = m0; m < m1; ++m) {
-            const ulonglong2 v = keys[m];
-#pragma unroll
-            for (int c = 0; c < DPT; ++c) {
-                cs[c] += (v.x < kx[c]);
-                if (WITH_Y) cy[c] += (v.y < ky[c]);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < DPT; ++c) {
-            if (kk[c] < nb) {
-                if (partial) {
-                    atomicAdd(&rank_s[kk[c]], cs[c]);
-                    if (WITH_Y) atomicAdd(&rank_y[kk[c]], cy[c]);
-                } else {
-                    rank_s[kk[c]] = cs[c];
-                    if (WITH_Y) rank_y[kk[c]] = cy[c];
-                }
-            }
-        }
-    }
-}
-
-struct LossParams {
-    const float *scores;
-    const void *rel;
-    const int64_t *n;
-    float *loss;
-    float *dscores;
-    int B, L;
-    float sigma;
-    int rel_dtype;
-    int msplit;
-    int sched;          // > 0: number of 64-query sample groups of the list-length scheduling
-};
-
-// LDS carve (bytes), L4 = L rounded up to 4:
-//   sy    float2[L4]          (score, label) -- for NDCG1 the label slot is overwritten by a_k
-//   q4    float4[L4]          NDCG2 only: (score, label, gain G, rank)
-//   delta float [L4 + 4]      NDCG2 only: |1/D(d) - 1/D(d+1)|, D(d) = log2(2+d)
-//   gpart float [msplit*L4]   per-slice gradient partials; aliased by the two int rank arrays
-//   red   float [32]
-__host__ __device__ inline size_t loss_lds_bytes(int kind, int L, int msplit)
-{
-    const size_t L4 = (size_t)((L + 3) & ~3);
-    size_t bytes = 8 * L4;
-    if (kind == LTR_NDCG2) bytes += 16 * L4 + 4 * (L4 + 4);
-    size_t g = 4 * L4 * (size_t)msplit;
-    if ((kind == LTR_NDCG1 || kind == LTR_NDCG2) && g < 8 * L4) g = 8 * L4;
-    // room behind the rank arrays for the packed keys of the counting rank (16 B per document)
-    if ((kind == LTR_NDCG1 || kind == LTR_NDCG2) && L4 <= 1024 && g < 24 * L4) g = 24 * L4;
-    return bytes + g + 32 * 4;
-}
-
-// LDS views of one query, carved from the dynamic segment (see loss_lds_bytes).
-struct QueryLds {
-    float2 *sy;
-    float4 *q4;
-    float *delta;
-    float *gpart;
-    int *rank_s;
-    int *rank_y;
-    float *red;
-    unsigned gbytes;      // bytes of the gpart region (the sort path borrows its tail)
-};
-
-template <int KIND>
-__device__ __forceinline__ QueryLds carve_query_lds(unsigned char *base, int L4, int msplit)
-{
-    QueryLds q;
-    q.sy = reinterpret_cast<float2 *>(base);
-    unsigned char *cur = base + 8 * (size_t)L4;
-    q.q4 = nullptr;
-    q.delta = nullptr;
-    if (KIND == LTR_NDCG2) {
-        q.q4 = reinterpret_cast<float4 *>(cur);
-        cur += 16 * (size_t)L4;
-        q.delta = reinterpret_cast<float *>(cur);
-        cur += 4 * (size_t)(L4 + 4);
-    }
-    q.gpart = reinterpret_cast<float *>(cur);
-    q.rank_s = reinterpret_cast<int *>(cur);      // aliases gpart (dead before gpart is written)
-    q.rank_y = q.rank_s + L4;
-    size_t g = 4 * (size_t)L4 * msplit;
-    if ((KIND == LTR_NDCG1 || KIND == LTR_NDCG2) && g < 8 * (size_t)L4) g = 8 * (size_t)L4;
-    if ((KIND == LTR_NDCG1 || KIND == LTR_NDCG2) && L4 <= 1024 && g < 24 * (size_t)L4) g = 24 * (size_t)L4;
-    cur += g;
-    q.gbytes = (unsigned)g;
-    q.red = reinterpret_cast<float *>(cur);
-    return q;
-}
-
-// NDCG kinds: ranks by score and by label, maxDCG, gains.  On return (barrier passed)
-//   NDCG1: sy[k].y = a_k = G_k / log2(2 + rank_k);   NDCG2: q4[k] = (s, y, G, rank), delta table.
-// TW > 0: the workgroup has TW waves (compile-time): the maxDCG sum takes one barrier instead of two.
-template <int KIND, int DPT, int TW = 0>
-__device__ __forceinline__ void prepare_ndcg(const QueryLds &q, int nb, int owners, int o, int m0,
-                                             int m1, bool partial)
-{
-    const int tid = threadIdx.x;
-    const int T = TW > 0 ? TW * 64 : (int)blockDim.x;
-    float2 *sy = q.sy;
-    // Lists longer than kSortRankMinLen: both rankings by a bitonic sort of packed (key, index)
-    // words (see sort_ranks) when the exchange buffer fits behind the rank arrays in the gpart
-    // region -- it always does on the symmetric path (L <= 1024); otherwise the counting rank.
-    const int L4r = (int)(q.rank_y - q.rank_s);
-    int Pq = 64;
-    while (Pq < nb) Pq <<= 1;
-    // (every thread writes its register(s) to the exchange buffer: max(Pq, T) or 4T words)
-    const unsigned xwords = (unsigned)(Pq <= T ? T : 4 * T);
-    const bool sorted = nb > kSortRankMinLen && Pq <= 4 * T &&
-                        q.gbytes >= 8u * (unsigned)L4r + 8u * xwords;
-    if (sorted) {
-        unsigned long long *xbuf = reinterpret_cast<unsigned long long *>(q.rank_s + 2 * L4r);
-        if (Pq <= T) {
-            unsigned long long v[1];
-            v[0] = (tid < nb) ? rank_key(sy[tid].x, tid) : ~0ull;
-            sort_ranks<1>(v, Pq, nb, q.rank_s, xbuf);
-            v[0] = (tid < nb) ? rank_key(sy[tid].y, tid) : ~0ull;
-            sort_ranks<1>(v, Pq, nb, q.rank_y, xbuf);
-        } else {
-            unsigned long long v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (e * T + tid < nb) ? rank_key(sy[e * T + tid].x, e * T + tid) : ~0ull;
-            sort_ranks<4>(v, Pq, nb, q.rank_s, xbuf);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (e * T + tid < nb) ? rank_key(sy[e * T + tid].y, e * T + tid) : ~0ull;
-            sort_ranks<4>(v, Pq, nb, q.rank_y, xbuf);
-        }
-    } else if (q.gbytes >= 24u * (unsigned)L4r) {
-        ulonglong2 *keys = reinterpret_cast<ulonglong2 *>(q.rank_s + 2 * L4r);   // behind the ranks
-        for (int k = tid; k < nb; k += T) {
-            const float2 v = sy[k];
-            keys[k] = make_ulonglong2(rank_key(v.x, k), rank_key(v.y, k));
-        }
-        __syncthreads();
-        count_ranks_keyed<DPT, true>(keys, nb, owners, o, m0, m1, partial, q.rank_s, q.rank_y);
-    } else {
-        count_ranks<DPT, true>(sy, nb, owners, o, m0, m1, partial, q.rank_s, q.rank_y);
-    }
-    __syncthreads();
-    // _max_dcg (loss/pairwise_lambda.py:231-241): labels sorted descending over the
-    // first n documents, gains 2^y - 1, discounts log2(2 + r).
-    float part = 0.f;
-    for (int k = tid; k < nb; k += T)
-        part += (exp2f(sy[k].y) - 1.0f) / log2f(2.0f + (float)q.rank_y[k]);
-    float maxdcg;
-    if (TW > 0) {
-        const float ws = wave_sum(part);
-        if ((tid & 63) == 0) q.red[tid >> 6] = ws;
-        __syncthreads();
-        maxdcg = 0.f;
-#pragma unroll
-        for (int i = 0; i < (TW > 0 ? TW : 1); ++i) maxdcg += q.red[i];
-    } else {
-        maxdcg = block_sum(part, q.red);
-    }
-    if (maxdcg == 0.0f) maxdcg = 1.0f;                     // pairwise_lambda.py:227
-    const float inv_maxdcg = 1.0f / maxdcg;
-    for (int k = tid; k < nb; k += T) {
-        const float2 v = sy[k];
-        const float G = (exp2f(v.y) - 1.0f) * inv_maxdcg;   // _ndcg_gains, :221-228
-        const int r = q.rank_s[k];
-        if (KIND == LTR_NDCG1)
-            sy[k].y = G / log2f(2.0f + (float)r);           // a_k = G_k / D(rank_k)
-        else
-            q.q4[k] = make_float4(v.x, v.y, G, (float)r);
-    }
-    if (KIND == LTR_NDCG2)
-        for (int d = tid; d < nb; d += T)                   // delta table, :206-211
-            q.delta[d] = fabsf(1.0f / log2f(2.0f + (float)d) - 1.0f / log2f(3.0f + (float)d));
-    __syncthreads();                                        // ranks dead from here: gpart may be written
-}
-
-// The per-query core shared by the loss kernel and the fused scorer kernel.
-// Precondition: q.sy[0..nb) = (score, label) is staged and visible (barrier passed); for the
-// NDCG kinds q.rank_s[0..2*L4) is zeroed.  Postcondition (after the trailing barrier):
-// q.gpart[slice*L4 + k] holds the slice partials of d(pair sum)/d s_k in units of `gscale`;
-// returns the final per-query loss (modifier applied) to every thread and, in `gsum`, the sum
-// over documents of d loss / d s_k (= d loss / d bias of a linear scorer; ~0 by construction).
-template <int KIND, int DPT, bool PIPE = true>
-__device__ __forceinline__ float pairwise_core(const QueryLds &q, int nb, int L4, int msplit,
-                                               float sigma, float &gscale, float &gsum)
-{
-    const int tid = threadIdx.x;
-    const int T = blockDim.x;
-    const int owners = T / msplit;                 // multiple of 64: slices are whole waves
-    const int o = tid % owners;
-    const int slice = tid / owners;
-    float2 *sy = q.sy;
-
-    // slice of the streamed index this thread's wave walks
-    // (slices are whole waves, so these bounds are wave-uniform: keep them in SGPRs)
-    const int mlen = ((nb + msplit - 1) / msplit + 1) & ~1;        // even: slices start 16-B aligned
-    const int m0 = __builtin_amdgcn_readfirstlane(min(nb, slice * mlen));
-    const int m1 = __builtin_amdgcn_readfirstlane(min(nb, m0 + mlen));
-    const float c1 = sigma * kLog2e;
-
-    if (KIND == LTR_NDCG1 || KIND == LTR_NDCG2)
-        prepare_ndcg<KIND, DPT>(q, nb, owners, o, m0, m1, msplit > 1);
-
-    // ---- pair pass ----
-    float lacc = 0.f, gacc = 0.f;
-    for (int base = 0; base < nb; base += owners * DPT) {
-        const int wave_first = base + (o & ~63);
-        if (wave_first >= nb) continue;                          // wave-uniform
-        float sk[DPT], yk[DPT], Gk[DPT], rk[DPT], gk[DPT];
-        int kk[DPT];
-#pragma unroll
-        for (int c = 0; c < DPT; ++c) {
-            kk[c] = base + o + c * owners;
-            const bool valid = kk[c] < nb;
-            gk[c] = 0.f; Gk[c] = 0.f; rk[c] = 0.f;
-            if (KIND == LTR_NDCG2) {
-                const float4 v = valid ? q.q4[kk[c]] : make_float4(0.f, __builtin_nanf(""), 0.f, 0.f);
-                sk[c] = v.x; yk[c] = v.y; Gk[c] = v.z; rk[c] = v.w;
-            } else if (KIND == LTR_ARP1 || KIND == LTR_NDCG1) {
-                const float2 v = valid ? sy[kk[c]] : make_float2(0.f, 0.f);   // a_k = 0: no loss
-                sk[c] = v.x; yk[c] = v.y;
-            } else {
-                // NaN label: both orientation tests fail -> an idle owner contributes nothing
-                const float2 v = valid ? sy[kk[c]] : make_float2(0.f, __builtin_nanf(""));
-                sk[c] = v.x; yk[c] = v.y;
-            }
-        }
-        // One streamed document against the DPT owned ones.
-        auto visit = [&](float sm, float ym, float Gm, float rm) {
-#pragma unroll
-            for (int c = 0; c < DPT; ++c) {
-                if (KIND == LTR_NDCG2) {
-                    const int d = (int)fabsf(rk[c] - rm);
-                    const float W = q.delta[d] * fabsf(Gk[c] - Gm);
-                    pair_oriented(sk[c], yk[c], sm, ym, W, c1, gk[c], lacc);
-                } else if (KIND == LTR_HINGE || KIND == LTR_DCG_HINGE) {
-                    pair_hinge(sk[c], yk[c], sm, ym, gk[c], lacc);
-                } else if (KIND == LTR_LOGISTIC) {
-                    pair_oriented(sk[c], yk[c], sm, ym, 1.0f, c1, gk[c], lacc);
-                } else if (KIND == LTR_ARP2) {
-                    pair_oriented(sk[c], yk[c], sm, ym, fabsf(yk[c] - ym), c1, gk[c], lacc);
-                } else {
-                    pair_rowweight(sk[c], yk[c], sm, ym, c1, gk[c], lacc);
-                }
-            }
-        };
-        // Streamed documents come from LDS in 64-byte chunks (4 x ds_read_b128, wave-uniform
-        // address = broadcast), software-pipelined one chunk ahead so the LDS latency hides under
-        // the pair arithmetic instead of stalling every iteration.
-        constexpr int MU = (KIND == LTR_NDCG2) ? 4 : 8;                  // documents per chunk
-        const float4 *src = (KIND == LTR_NDCG2) ? q.q4 : reinterpret_cast<const float4 *>(sy);
-        constexpr int VPD = (KIND == LTR_NDCG2) ? 1 : 2;                 // documents per float4
-        // PIPE = false (register-tight callers): plain loop, no prefetch registers
-        const int mfull = PIPE ? m0 + ((m1 - m0) / MU) * MU : m0;        // m0 is even (see mlen)
-        if (mfull > m0) {
-            float4 cur[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) cur[j] = src[m0 / VPD + j];
-            for (int m = m0; m < mfull; m += MU) {
-                const int mn = (m + MU < mfull) ? (m + MU) : m;          // last chunk: harmless re-read
-                float4 nxt[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) nxt[j] = src[mn / VPD + j];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (KIND == LTR_NDCG2) {
-                        visit(cur[j].x, cur[j].y, cur[j].z, cur[j].w);
-                    } else {
-                        visit(cur[j].x, cur[j].y, 0.f, 0.f);
-                        visit(cur[j].z, cur[j].w, 0.f, 0.f);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
-            }
-        }
-        for (int m = mfull; m < m1; ++m) {                               // remainder (< MU documents)
-            if (KIND == LTR_NDCG2) {
-                const float4 v = q.q4[m];
-                visit(v.x, v.y, v.z, v.w);
-            } else {
-                const float2 v = sy[m];
-                visit(v.x, v.y, 0.f, 0.f);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < DPT; ++c)
-            if (kk[c] < nb) { q.gpart[(size_t)slice * L4 + kk[c]] = gk[c]; gacc += gk[c]; }
-    }
-
-    // ---- per-query reduction (loss and gradient sum in one pass) and loss modifier ----
-    float total = lacc;
-    block_sum2(total, gacc, q.red);           // its barriers publish gpart when there are >= 2 waves
-    if (T == kWave) __syncthreads();
-    gscale = 1.0f;
-    if (KIND == LTR_DCG_HINGE) {
-        // _loss_modifier (loss/pairwise_additive.py:132-133): -1/ln(2+H);
-        // d/dH = 1/((2+H) ln^2(2+H))
-        const float lg = logf(2.0f + total);
-        gscale = 1.0f / ((2.0f + total) * lg * lg);
-        total = -1.0f / lg;
-    } else if (KIND != LTR_HINGE) {
-        gscale = sigma / kLn2;
-    }
-    gsum = gacc * gscale;
-    return total;
-}
-
-// ---------------------------------------------------------------------------------
-// Symmetric pair pass (list_len <= kSymMaxLen): every UNORDERED pair is evaluated once.
-// Documents are cut into 64-wide tiles; a job is an unordered tile pair (a, b).  A wave keeps
-// the "home" tile a in registers (lane i = document 64a+i) and a "visitor" tile b that ROTATES
-// through the lanes: at step j lane i holds visitor 64b + ((i+j) & 63) -- its score, label and
-// its gradient accumulator travel together, one v_mov_b32_dpp wave_rol:1 each per step (no LDS,
-// no atomics).  One evaluation of the pair term updates the home gradient (+c) and the visitor
-// gradient (-c): every loss on this path depends on score DIFFERENCES only, so the two
-// contributions are exact negatives.  Diagonal jobs take j = 1..32 (the last step on half the
-// lanes), off-diagonal jobs j = 0..63: 32*nt^2 steps in all, split evenly over the waves; each
-// wave flushes into its PRIVATE gpart slice (deterministic).  This halves the VALU work of the
-// both-ends formulation (pairwise_core), which remains the path for longer lists.
-// Inert documents (index >= n[b]) carry NaN sentinels: NaN label for the oriented kinds (both
-// label tests fail), NaN score for the row-weight kinds (detected with x == x).
-// Precondition: sy[0..nb) staged (q4/delta/a_k prepared for the NDCG kinds), Lt = 64*ceil(L/64).
-// Postcondition (after the trailing barrier): gpart[w*Lt + k], w < blockDim/64, hold partials of
-// d(pair sum)/d s_k in units of gscale; returns the per-query loss.
-// ---------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_rol1(float v)
-{
-    // lane i <- lane (i+1) & 63; every lane has a valid source, so no "old" value is needed
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x134, 0xF, 0xF, true));
-}
-
-// part / parts: this workgroup is one of `parts` that share the query's pair units (split-query
-// launch); raw: return the plain pair sum (no loss modifier, gscale untouched).
-// TW > 0: the workgroup has TW waves (compile-time: no dispatch-packet read, shifts instead of
-// divisions) and, when it owns the whole query, only as many of them take pair units as the query
-// has work for (at least LTR_SYM_MIN_STEPS steps per wave, a power of two of waves).  Measured (C2,
-// fused hinge step, us): 1 step per wave 11.3, 4: 11.6, 8: 11.9, 16: 12.3 -- the pass is latency-
-// bound, more waves with fewer steps each win, so the default is 1 (every wave that can get a step).
-// Idle waves still publish a zero gradient slice.
-#ifndef LTR_SYM_MIN_STEPS
-#define LTR_SYM_MIN_STEPS 1
-#endif
-#ifdef LTR_TRACE
-#define LTR_SYM_STAMP(i) do { if (trace && threadIdx.x == 0) trace[i] = (long long)wall_clock64(); } while (0)
-#else
-#define LTR_SYM_STAMP(i) do { } while (0)
-#endif
-template <int KIND, int TW = 0>
-__device__ __forceinline__ float pairwise_core_sym(const QueryLds &q, int nb, int Lt, float sigma,
-                                                   float &gscale, int part = 0, int parts = 1,
-                                                   bool raw = false, long long *trace = nullptr)
-{
-    const int tid = threadIdx.x;
-    const int T = TW > 0 ? TW * 64 : (int)blockDim.x;
-    const int lane = tid & 63;
-    const int wl = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int w = part * (T >> 6) + wl;                            // wave index among all parts
-    int W = parts * (T >> 6);
-    const int nt = (nb + 63) >> 6;
-    const float c1 = sigma * kLog2e;
-    constexpr bool kRowWeight = (KIND == LTR_ARP1 || KIND == LTR_NDCG1);
-    const float kNaN = __builtin_nanf("");
-    float *gw = q.gpart + (size_t)wl * Lt;
-    for (int i = lane; i < 64 * nt; i += 64) gw[i] = 0.f;
-
-    float lacc = 0.f;
-    // Steps per job: off-diagonal 64 (j = 0..63); diagonal 32 (j = 1..32), except that the last,
-    // partially filled tile only has pairs at j < hc (hc = its document count) while hc <= 32.
-    const int hc_last = nb - 64 * (nt - 1);
-    const int dlast = (hc_last - 1 < 32) ? (hc_last - 1) : 32;
-    const int S = (nt > 0) ? (32 * nt * nt - (32 - dlast)) : 0;
-    int u, u1;
-    if (TW > 0 && parts == 1 && (TW & (TW - 1)) == 0) {
-        // waves that take units: the largest power of two <= S / LTR_SYM_MIN_STEPS, in [1, TW]
-        int sh = 0;
-        while ((2 << sh) <= TW && (2 << sh) * LTR_SYM_MIN_STEPS <= S) ++sh;
-        W = 1 << sh;
-        u = (wl * S) >> sh;
-        u1 = (wl < W) ? ((wl + 1) * S) >> sh : u;
-        if (wl >= W) u = u1 = 0;
-        w = wl;
-    } else if (TW > 0 && parts == 1) {
-        u = (wl * S) / TW;                                   // (division by a constant)
-        u1 = ((wl + 1) * S) / TW;
-    } else {
-        u = (w * S) / W;
-        u1 = ((w + 1) * S) / W;
-    }
-    // decode the first unit of this wave into (a, b, j): row a of the job triangle holds its
-    // diagonal job (32 steps, dlast in the last row) and 64 steps for every b > a -- walk the rows
-    // (<= nt iterations), then the column is a division (a job-by-job walk cost up to nt^2/2
-    // iterations per wave, a quarter of a split-launch part's whole work at n = 1000)
-    int a = 0, rem = u;
-    while (a < nt - 1) {
-        const int rowlen = 32 + 64 * (nt - 1 - a);
-        if (rem < rowlen) break;
-        rem -= rowlen;
-        ++a;
-    }
-    int b = a;
-    {
-        const int dl = (a == nt - 1) ? dlast : 32;
-        if (rem >= dl && a < nt - 1) {
-            rem -= dl;
-            b = a + 1 + (rem >> 6);
-            rem &= 63;
-        }
-    }
-    int j = ((a == b) ? 1 : 0) + rem;
-    LTR_SYM_STAMP(0);                                        // slices zeroed, units decoded
-
-    while (u < u1) {
-        const bool diag = (a == b);
-        const int jend = diag ? (1 + ((a == nt - 1) ? dlast : 32)) : 64;
-        // ---- load the home tile of this segment ----
-        const int hidx = 64 * a + lane;
-        const bool hvalid = hidx < nb;
-        float sh, yh, Gh = 0.f, rh = 0.f;
-        if (KIND == LTR_NDCG2) {
-            const float4 hv = q.q4[hvalid ? hidx : 0];
-            sh = hv.x; yh = hvalid ? hv.y : kNaN; Gh = hv.z; rh = hv.w;
-        } else {
-            const float2 hv = q.sy[hvalid ? hidx : 0];
-            if (kRowWeight) { sh = hvalid ? hv.x : kNaN; yh = hv.y; }
-            else { sh = hv.x; yh = hvalid ? hv.y : kNaN; }
-        }
-        float gh = 0.f;
-        // A visitor chain: the visitor tile rotated by `rot` lanes, its gradient accumulator travelling
-        // with it.  LambdaNDCG2: the discount difference delta(|rank_home - rank_visitor|) comes
-        // from an LDS table; it is fetched ONE STEP AHEAD (the next visitor's rank is one rotation
-        // away), so the LDS round trip is off the dependency chain of the step.
-        struct Vis { float sv, yv, Gv, rv, gv, dcur; };
-        auto load_vis = [&](Vis &V, int rot) {
-            const int vidx = 64 * b + ((lane + rot) & 63);
-            const bool vvalid = vidx < nb;
-            V.Gv = 0.f; V.rv = 0.f; V.gv = 0.f; V.dcur = 0.f;
-            if (KIND == LTR_NDCG2) {
-                const float4 vv = q.q4[vvalid ? vidx : 0];
-                V.sv = vv.x; V.yv = vvalid ? vv.y : kNaN; V.Gv = vv.z; V.rv = vv.w;
-                V.dcur = q.delta[(int)fabsf(rh - V.rv)];
-            } else {
-                const float2 vv = q.sy[vvalid ? vidx : 0];
-                if (kRowWeight) { V.sv = vvalid ? vv.x : kNaN; V.yv = vv.y; }
-                else { V.sv = vv.x; V.yv = vvalid ? vv.y : kNaN; }
-            }
-        };
-        // one evaluation of the pair (home, visitor); `half`: only lanes < 32 count (j == 32)
-        auto visit = [&](Vis &V, bool half) {
-            const float sv = V.sv, yv = V.yv;
-            const bool on = half ? (lane < 32) : true;
-            float c;                                             // d term / d s_home
-            if (KIND == LTR_HINGE || KIND == LTR_DCG_HINGE) {
-                // sgn = -1 when the home document is the higher-labelled one, +1 when the visitor is,
-                // 0 when the labels are equal or one of them is the NaN sentinel (ordered compares);
-                // margin term u = |sgn| + sgn*(s_home - s_vis): 0 for an inert pair; the pair counts
-                // iff u >= 0 (non-strict, as the reference leaves the gradient at the margin) -- one
-                // compare feeding selects, no scalar mask arithmetic in the dependency chain
-                float sgn = (yh < yv) ? 1.0f : 0.0f;
-                sgn = (yh > yv) ? -1.0f : sgn;
-                if (half) sgn = on ? sgn : 0.0f;
-                const float uu = __builtin_fmaf(sgn, sh - sv, __builtin_fabsf(sgn));
-                lacc += __builtin_fmaxf(uu, 0.0f);
-                c = (uu >= 0.0f) ? sgn : 0.0f;
-            } else if (!kRowWeight) {
-                const bool gt = yh > yv, lt = yh < yv;
-                float Wp = 1.0f;
-                if (KIND == LTR_ARP2) Wp = fabsf(yh - yv);
-                if (KIND == LTR_NDCG2) Wp = V.dcur * fabsf(Gh - V.Gv);
-                const float t = (sh - sv) * c1;
-                const float z = gt ? t : -t;
-                const float e = __builtin_amdgcn_exp2f(-fabsf(z));
-                const float r = __builtin_amdgcn_rcpf(1.0f + e);
-                const float psi = (z >= 0.0f) ? e * r : r;
-                const float lg = log2_1p(e) + fmaxf(-z, 0.0f);
-                const float Wm = (on & (gt | lt)) ? Wp : 0.0f;
-                lacc += Wm * lg;
-                c = (gt ? -Wm : Wm) * psi;
-            } else {
-                const float x = (sh - sv) * c1;
-                const bool ok = on & (x == x);                   // NaN score = inert document
-                const float e = __builtin_amdgcn_exp2f(-fabsf(x));
-                const float r = __builtin_amdgcn_rcpf(1.0f + e);
-                const float sneg = (x >= 0.0f) ? e * r : r;
-                const float l1 = log2_1p(e);
-                const float both = yh * (l1 + fmaxf(-x, 0.0f)) + yv * (l1 + fmaxf(x, 0.0f));
-                lacc += ok ? both : 0.0f;
-                c = ok ? (yv - (yh + yv) * sneg) : 0.0f;
-            }
-            gh += c;
-            V.gv -= c;
-        };
-        auto rotate = [&](Vis &V) {
-            V.sv = wave_rol1(V.sv); V.yv = wave_rol1(V.yv); V.gv = wave_rol1(V.gv);
-            if (KIND == LTR_NDCG2) { V.Gv = wave_rol1(V.Gv); V.rv = wave_rol1(V.rv); }
-        };
-        // a full step of a chain (the discount of the NEXT step requested first)
-        auto step = [&](Vis &V) {
-            float dnext = 0.f;
-            if (KIND == LTR_NDCG2) dnext = q.delta[(int)fabsf(rh - wave_rol1(V.rv))];
-            visit(V, false);
-            rotate(V);
-            V.dcur = dnext;
-        };
-        auto flush_vis = [&](const Vis &V, int rot) {
-            const int fidx = 64 * b + ((lane + rot) & 63);       // the visitor now in this lane
-            if (fidx < nb) gw[fidx] += V.gv;
-        };
-
-        const int steps = min(jend - j, u1 - u);
-        u += steps;
-        const int jstop = j + steps;
-        // full steps (every lane), then at most one half step (diagonal job, j == 32): the LAST step
-        const bool has_half = diag && jstop == 33;
-        // (Two visitor chains per lane -- the steps [j, j+n/2) and [j+n/2, jstop) interleaved, two
-        // independent dependency chains -- were measured and dropped: correct, but 2-10 % slower in
-        // every kernel (C2 fused hinge 10.5 -> 11.2 us, LambdaNDCG2 16.2 -> 16.6, 256 x 1000 hinge
-        // loss 49.7 -> 56.2): the second chain's registers and moves cost more than its ILP buys.)
-        {
-            Vis A;
-            load_vis(A, j);
-            const int jfull = has_half ? 32 : jstop;
-            for (; j < jfull; ++j) step(A);
-            if (has_half) { visit(A, true); rotate(A); ++j; }
-            if (hvalid) gw[hidx] += gh;
-            flush_vis(A, j);
-        }
-        if (j == jend) {
-            if (++b == nt) { ++a; b = a; }
-            j = (a == b) ? 1 : 0;
-        }
-    }
-    if (kRowWeight && part == 0)              // the i == j terms: a_i * log2(1 + e^0) = a_i
-        for (int k = tid; k < nb; k += T) lacc += q.sy[k].y;
-    LTR_SYM_STAMP(1);                                        // steps done, accumulators flushed (wave 0)
-
-    float total;
-    if (TW > 0) {
-        // every wave parks its sum in its own slot (the upper half of `red`: no reuse hazard with the
-        // block sums of prepare_ndcg), ONE barrier publishes the sums and the gradient slices
-        const float ws = wave_sum(lacc);
-        if (lane == 0) q.red[16 + wl] = ws;
-        __syncthreads();
-        LTR_SYM_STAMP(2);                                    // barrier passed
-        total = 0.f;
-#pragma unroll
-        for (int i = 0; i < (TW > 0 ? TW : 1); ++i) total += q.red[16 + i];
-    } else {
-        total = block_sum(lacc, q.red);       // its barriers publish gpart when there are >= 2 waves
-        if (T == kWave) __syncthreads();
-    }
-    if (raw) return total;
-    gscale = 1.0f;
-    if (KIND == LTR_DCG_HINGE) {
-        const float lg = logf(2.0f + total);
-        gscale = 1.0f / ((2.0f + total) * lg * lg);
-        total = -1.0f / lg;
-    } else if (KIND != LTR_HINGE) {
-        gscale = sigma / kLn2;
-    }
-    return total;
-}
+namespace {
 
 // NW > 0 (symmetric pass only): the workgroup has NW waves, known at compile time (4 / 8 / 16 by
 // list length) -- the pair pass then needs no dispatch-packet read, no divisions and one barrier less.
@@ -1113,26 +156,6 @@ pairwise_loss_kernel(LossParams p)
 // and scales the gradient.  Parts beyond what a short query can use exit at once.
 // workspace: float loss_part[B][nsplit], then float grad_part[B][nsplit][L].
 // ---------------------------------------------------------------------------------
-#ifndef LTR_SPLIT_WAVES
-#define LTR_SPLIT_WAVES 4
-#endif
-#ifndef LTR_SPLIT_MAX
-#define LTR_SPLIT_MAX 8
-#endif
-#ifndef LTR_SPLIT_MIN_STEPS
-#define LTR_SPLIT_MIN_STEPS 16
-#endif
-__host__ __device__ inline int split_parts_for(int nb, int nsplit, int waves)
-{
-    // a part should have at least ~16 pair steps per wave to be worth a workgroup (swept 8..96 with the
-    // list-length order in place: C4 hinge 34.7 us at 96, 31.7 at 48, 28.4 at 16)
-    const int nt = (nb + 63) >> 6;
-    const int units = 32 * nt * nt;
-    int e = units / (LTR_SPLIT_MIN_STEPS * waves);
-    e = e < 1 ? 1 : e;
-    return e < nsplit ? e : nsplit;
-}
-
 // Rankings of the NDCG kinds for the split-query launch, once per query (the parts of a query
 // would each repeat two 1024-element sorts): one 1024-thread workgroup stages the row, runs
 // prepare_ndcg and leaves per document (a_k, 0) for LambdaNDCG1 or (G_k / maxDCG, rank_k) for
@@ -1744,30 +767,6 @@ __global__ void collate_pad_kernel(const V *__restrict__ xs, const int64_t *__re
     }
 }
 
-// ---------------------------------------------------------------------------------
-// host side: launch-shape heuristic and dispatch
-// ---------------------------------------------------------------------------------
-// (64 bytes short of the CU's 160 KB: kernels that use sched_query_sampled carry 8 bytes of static
-// LDS, and static + dynamic must fit together)
-constexpr size_t kLdsBudget = 160 * 1024 - 64;
-// Raise a kernel's dynamic-LDS limit above the 64 KiB default once per device (the attribute is
-// sticky), so steady-state launches -- including hipGraph capture -- issue no extra API calls.
-constexpr int kMaxDevices = 64;
-#define LTR_ENSURE_LDS(KERNEL, BYTES)                                                           \
-    do {                                                                                        \
-        static size_t cfg_[kMaxDevices] = {};                                                   \
-        int dev_ = 0;                                                                           \
-        (void)hipGetDevice(&dev_);                                                              \
-        if ((size_t)(BYTES) > 64 * 1024 && dev_ >= 0 && dev_ < kMaxDevices &&                   \
-            (size_t)(BYTES) > cfg_[dev_]) {                                                     \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL),        \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                                (int)kLdsBudget);                               \
-            if (e_ != hipSuccess) return (int)e_;                                               \
-            cfg_[dev_] = kLdsBudget;                                                            \
-        }                                                                                       \
-    } while (0)
-
 struct LaunchShape { int owners, dpt, msplit; };
 
 // dpt == 0: symmetric pair pass -- LDS rows padded to 64-wide tiles, one gradient slice per wave
@@ -1862,45 +861,6 @@ int launch_loss(int kind, const LossParams &p, const LaunchShape &s, hipStream_t
     }
 }
 
-inline int device_cu_count()
-{
-    static int cached[kMaxDevices] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= kMaxDevices) dev = 0;
-    if (cached[dev] == 0) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-            v = 256;
-        cached[dev] = v;
-    }
-    return cached[dev];
-}
-
-// Number of sample groups for sched_query_sampled, or 0 = plain order: worth it with more than one
-// workgroup per CU and up to `max_per_cu` of them (beyond that the order stops mattering).
-inline int sched_groups(int B, int max_per_cu)
-{
-#ifdef LTR_NO_SCHED
-    (void)B; (void)max_per_cu;
-    return 0;
-#else
-    const int cus = device_cu_count();
-    return (B > cus + cus / 8 && (long long)B <= (long long)max_per_cu * cus) ? (B + 63) / 64 : 0;
-#endif
-}
-
-// The loss kernel and the general fused kernel: the pass costs ~0.3 us per launch, which short
-// lists do not win back (L = 64: 5.0 -> 5.2 us at B = 1024); lists of 128 need a full chip
-// (B >= 4 x #CUs: hinge 7.0 -> 6.7, LambdaNDCG2 15.0 -> 13.2), longer ones always gain (L = 512,
-// B = 1024: hinge 37 -> 28 us, logistic 75 -> 55, LambdaNDCG2 148 -> 120; profiles/README.md).
-inline int sched_groups_for_lists(int B, int L)
-{
-    if (L <= 64) return 0;
-    if (L < 256 && B < 4 * device_cu_count()) return 0;
-    return sched_groups(B, LTR_LOSS_SCHED_MAX_PER_CU);
-}
-
 // How many workgroups share a query in the split launch (1 = use the one-kernel path): long lists
 // only, and only while the batch alone cannot give every CU several queries to balance with.
 constexpr int kSplitWaves = LTR_SPLIT_WAVES;   // waves per part: small workgroups, many per CU
@@ -1990,16 +950,6 @@ int launch_metric(const MetricParams &p0, hipStream_t stream)
     }
 #undef LTR_LAUNCH
     return (int)hipGetLastError();
-}
-
-inline bool bad_label_dtype(int d) { return d != LTR_LABEL_I64 && d != LTR_LABEL_F32 && d != LTR_LABEL_I32; }
-
-inline unsigned grid_for(size_t items, int block)
-{
-    size_t g = (items + (size_t)block - 1) / (size_t)block;
-    if (g < 1) g = 1;
-    if (g > 2048) g = 2048;          // 256 CUs x 8 blocks, grid-stride the rest
-    return (unsigned)g;
 }
 
 }  // namespace
@@ -2337,7 +1287,4 @@ int ltr_collate_pad_f32(const float *xs, const int64_t *ys, const int64_t *offse
 
 }  // extern "C"
 
-#include "ltr_linear.inc"
 #include "ltr_f64.inc"
-#include "ltr_mlp.inc"
-#include "ltr_scorer.inc"

@@ -75,6 +75,19 @@ def test_fused_step_large_tiles(shape):
     _check(kind, B, L, F, 8)                     # tile does not fit LDS: re-read path
 
 
+@pytest.mark.parametrize("shape", [(5, 8, 2048, "hinge"), (5, 12, 2048, "logistic"),
+                                   (5, 16, 1024, "ndcg2"), (4, 18, 1024, "ndcg1")])
+def test_fused_step_rows_as_wide_as_the_workgroup(shape):
+    """A row with as many 16-byte column vectors as the workgroup has threads (C == T: F = 2048 on the
+    512-thread register tile, F = 1024 on the 256-thread NDCG tile): the bias partial must still be
+    written (it was stored by thread C, which does not exist there)."""
+    B, L, F, kind = shape
+    from pytorchltr_amd import _C
+    assert _C.lib().ltr_linear_fused_plan(_C.KINDS[kind], B, L, F) == _C.PLAN_REGISTER_TILE
+    _check(kind, B, L, F, 17)
+    _check(kind, B, L, F, 18, grad_out=torch.linspace(-1.0, 2.0, B))
+
+
 @pytest.mark.parametrize("name", [c["name"] for c in G.by_op("linear_step")])
 def test_fused_step_vs_reference_vectors(name):
     """Against what the real reference computed for loss_fn(Linear(X), y, n).mean().backward()."""
