@@ -83,7 +83,7 @@ def test_fused_step_rows_as_wide_as_the_workgroup(shape):
     written (it was stored by thread C, which does not exist there)."""
     B, L, F, kind = shape
     from pytorchltr_amd import _C
-    assert _C.lib().ltr_linear_fused_plan(_C.KINDS[kind], B, L, F) == _C.PLAN_REGISTER_TILE
+    assert _C.lib().ltr_linear_fused_plan(O.KINDS[kind], B, L, F) == _C.PLAN_REGISTER_TILE
     _check(kind, B, L, F, 17)
     _check(kind, B, L, F, 18, grad_out=torch.linspace(-1.0, 2.0, B))
 
