@@ -63,7 +63,8 @@ WORKLOADS = {
     "c4": (256, 1000, 220, "dcg_hinge"),
     "c5": (512, 512, 700, "hinge"),
 }
-PLAN_NAMES = {1: "linear_regtile_kernel", 2: "linear_cluster_kernel", 3: "linear_pairwise_kernel"}
+PLAN_NAMES = {1: "linear_regtile_kernel", 2: "linear_cluster_kernel", 3: "linear_pairwise_kernel",
+              4: "linear_parts_kernel"}
 
 
 def synth(B, L, F, seed, device):

@@ -251,7 +251,7 @@ size_t ltr_linear_workspace_bytes(int B, int L, int F);
  * output is requested and X is 16-byte aligned: the register tile (features cross HBM once, one
  * workgroup per query), the cluster kernel (features once, a query spread over several workgroups:
  * long lists on small batches, rank-free kinds) or the general kernel (features twice). */
-enum { LTR_PLAN_NONE = 0, LTR_PLAN_REGISTER_TILE = 1, LTR_PLAN_CLUSTER = 2, LTR_PLAN_GENERAL = 3 };
+enum { LTR_PLAN_NONE = 0, LTR_PLAN_REGISTER_TILE = 1, LTR_PLAN_CLUSTER = 2, LTR_PLAN_GENERAL = 3, LTR_PLAN_PARTS = 4 };
 int ltr_linear_fused_plan(int kind, int B, int L, int F);
 int ltr_linear_pairwise_f32(int kind, float sigma, const float *X, const float *W,
                             const float *bias, const void *rel, int rel_dtype,

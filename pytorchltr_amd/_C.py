@@ -18,7 +18,7 @@ HINGE, DCG_HINGE, LOGISTIC, ARP1, ARP2, NDCG1, NDCG2 = range(7)
 LABEL_I64, LABEL_F32, LABEL_I32 = 0, 1, 2
 ERR_TIMEOUT = -7
 # ltr_linear_fused_plan (include/ltr_hip.h)
-PLAN_NONE, PLAN_REGISTER_TILE, PLAN_CLUSTER, PLAN_GENERAL = 0, 1, 2, 3
+PLAN_NONE, PLAN_REGISTER_TILE, PLAN_CLUSTER, PLAN_GENERAL, PLAN_PARTS = 0, 1, 2, 3, 4
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 

@@ -1,9 +1,11 @@
 """GPU tier: the long-list fused configs at BASELINE's FULL sizes against the oracle on every row
 (VERDICT r1 item 2): C4 256 x 1000 x 220 PairwiseDCGHingeLoss on the cluster kernel (a query spread
 over several workgroups that wait for each other), C5 512 x 512 x 700 PairwiseHingeLoss on the
-general kernel -- each run twice (bit-identical) and, for the cluster kernel, once more while a
-second stream keeps the GPU busy; plus the failure mode of the in-launch waits: a wait that gives
-up must surface as LTR_ERR_TIMEOUT, not as a silent NaN.
+parts kernel (round 3: features read once; the general kernel on a narrower twin) -- each run twice
+(bit-identical) and, for the kernels whose workgroups wait for each other, three more times while a
+second stream keeps the GPU busy; workspace reuse and graph replay of the parts kernel's self-resetting
+control block; plus the failure mode of the in-launch waits: a wait that gives up must surface as
+LTR_ERR_TIMEOUT, not as a silent NaN.
 Reference: loss/pairwise_additive.py:51-90,116-133 composed with torch.nn.Linear
 (examples/01-basic-usage.py:66-75)."""
 import numpy as np
@@ -68,9 +70,94 @@ def test_c4_shard_of_8_gpus_cluster_kernel():
     _run("dcg_hinge", 32, 1000, 220, 1, _C.PLAN_CLUSTER)
 
 
-def test_c5_full_size_general_kernel_all_rows():
+def test_c5_full_size_parts_kernel_all_rows():
+    """C5 at full size on the parts kernel (features read once, one exchange per query, persistent
+    workgroups drawing tickets): every row against the oracle, run twice (bit-identical) and three more
+    times while a second stream keeps the CUs busy (fewer of the persistent workgroups resident)."""
     from pytorchltr_amd import _C
-    _run("hinge", 512, 512, 700, 0, _C.PLAN_GENERAL)
+    _run("hinge", 512, 512, 700, 0, _C.PLAN_PARTS, busy=True)
+
+
+def test_c5_full_size_general_kernel_all_rows():
+    """The same step on the general kernel (features read twice): LTR_DISABLE_PARTS is read once per
+    process, so the general kernel is reached through the shape rule instead -- rows of 220 features."""
+    from pytorchltr_amd import _C
+    _run("hinge", 512, 512, 220, 0, _C.PLAN_GENERAL)
+
+
+@pytest.mark.parametrize("shape", [("hinge", 48, 2000, 64), ("dcg_hinge", 20, 4000, 32), ("logistic", 300, 512, 700),
+                                   ("arp1", 400, 600, 512), ("arp2", 600, 300, 448)])
+def test_parts_kernel_shapes_all_rows(shape):
+    """Long lists (beyond the symmetric pass) and wide rows, every rank-free kind, all rows."""
+    from pytorchltr_amd import _C
+    kind, B, L, F = shape
+    _run(kind, B, L, F, 4, _C.PLAN_PARTS)
+
+
+def test_parts_kernel_reuses_a_workspace_across_batches_and_shapes():
+    """The control block and the tagged score granules live in the caller's workspace and reset
+    themselves: the same buffer serves different batches, then a different shape (its control block
+    lands elsewhere and is brought up again), then the first shape again -- each step against the
+    oracle; a stale granule or counter from an earlier launch would show up here."""
+    from pytorchltr_amd import _C
+    dev = _dev()
+    lib = _C.lib()
+    shapes = [(70, 512, 700), (70, 512, 700), (33, 2000, 64), (70, 512, 700), (200, 400, 512), (33, 2000, 64)]
+    nbytes = max(lib.ltr_linear_workspace_bytes(*sh) for sh in shapes)
+    ws = torch.empty(nbytes // 4 + 64, device=dev).fill_(float("nan"))
+    for i, (B, L, F) in enumerate(shapes):
+        assert lib.ltr_linear_fused_plan(_C.HINGE, B, L, F) == _C.PLAN_PARTS
+        s, y, n, X, W, b = synth(B, L, 100 + i, F=F)
+        Xd, Wd, bd, yd, nd = X.to(dev), W.to(dev), b.to(dev), y.to(dev), n.to(dev)
+        loss = torch.empty(B, device=dev)
+        dW, db = torch.empty(F, device=dev), torch.empty(1, device=dev)
+        for rep in range(2):
+            _C.check(lib.ltr_linear_pairwise_f32(_C.HINGE, 1.0, Xd.data_ptr(), Wd.data_ptr(), bd.data_ptr(),
+                                                 yd.data_ptr(), _C.LABEL_I64, nd.data_ptr(), None, B, L, F,
+                                                 loss.data_ptr(), None, dW.data_ptr(), db.data_ptr(),
+                                                 ws.data_ptr(), nbytes, _C.stream_of(Xd)))
+        want_l, _, want_dW, want_db = O.linear_pairwise("hinge", X.numpy(), W.numpy(), float(b[0]), y.numpy(),
+                                                        n.numpy(), np.full(B, 1.0 / B))
+        assert np.allclose(loss.cpu().numpy(), want_l, rtol=5e-4, atol=1e-5), (i, B, L, F)
+        assert np.max(np.abs(dW.cpu().numpy() - want_dW)) < 2e-4 * max(1.0, float(np.max(np.abs(want_dW))))
+    _C.device_status()
+
+
+def test_parts_kernel_under_graph_replay():
+    """hipGraph replay freezes the kernel arguments: the tag of the score granules must come from device
+    state (the epoch in the control block), or a replay would accept the previous replay's scores."""
+    from pytorchltr_amd import _C
+    dev = _dev()
+    lib = _C.lib()
+    B, L, F = 80, 512, 700
+    assert lib.ltr_linear_fused_plan(_C.DCG_HINGE, B, L, F) == _C.PLAN_PARTS
+    s, y, n, X, W, b = synth(B, L, 31, F=F)
+    Xd, Wd, bd, yd, nd = X.to(dev), W.to(dev), b.to(dev), y.to(dev), n.to(dev)
+    nbytes = lib.ltr_linear_workspace_bytes(B, L, F)
+    ws = torch.empty(nbytes // 4 + 64, device=dev)
+    loss = torch.empty(B, device=dev)
+    dW, db = torch.empty(F, device=dev), torch.empty(1, device=dev)
+
+    def step():
+        _C.check(lib.ltr_linear_pairwise_f32(_C.DCG_HINGE, 1.0, Xd.data_ptr(), Wd.data_ptr(), bd.data_ptr(),
+                                             yd.data_ptr(), _C.LABEL_I64, nd.data_ptr(), None, B, L, F,
+                                             loss.data_ptr(), None, dW.data_ptr(), db.data_ptr(),
+                                             ws.data_ptr(), nbytes, _C.stream_of(Xd)))
+    step()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    for rep in range(3):
+        # new weights for every replay (same addresses): the scores change, stale granules would not
+        Wd.copy_(W.to(dev) * (1.0 + rep))
+        g.replay()
+        torch.cuda.synchronize()
+        want_l, _, want_dW, _ = O.linear_pairwise("dcg_hinge", X.numpy(), W.numpy() * (1.0 + rep), float(b[0]),
+                                                  y.numpy(), n.numpy(), np.full(B, 1.0 / B))
+        assert np.allclose(loss.cpu().numpy(), want_l, rtol=5e-4, atol=1e-5), rep
+        assert np.max(np.abs(dW.cpu().numpy() - want_dW)) < 2e-4 * max(1.0, float(np.max(np.abs(want_dW)))), rep
+    _C.device_status()
 
 
 def test_c5_shard_of_8_gpus():
@@ -79,16 +166,19 @@ def test_c5_shard_of_8_gpus():
     _run("hinge", 64, 512, 700, 2, plan)
 
 
-def test_cluster_wait_timeout_is_an_error_not_a_silent_nan():
+@pytest.mark.parametrize("shape", [(32, 1000, 220, "cluster"), (300, 512, 700, "parts")])
+def test_cluster_wait_timeout_is_an_error_not_a_silent_nan(shape):
     """ltr_debug_force_timeout makes every in-launch wait give up: the step's outputs are poisoned
-    AND the sticky status word turns the next ltr_linear_* call into LTR_ERR_TIMEOUT."""
+    AND the sticky status word turns the next ltr_linear_* call into LTR_ERR_TIMEOUT.  Both kernels
+    whose workgroups wait for each other: the cluster kernel and the parts kernel (which also drops its
+    control block, so that the next launch brings it up again)."""
     from pytorchltr_amd import _C
     from pytorchltr_amd.fused import linear_loss_step
     dev = _dev()
-    B, L, F = 32, 1000, 220
+    B, L, F, which = shape
     s, y, n, X, W, b = synth(B, L, 3, F=F)
     args = (X.to(dev), W.to(dev), b.to(dev), y.to(dev), n.to(dev))
-    assert _C.lib().ltr_linear_fused_plan(_C.HINGE, B, L, F) == _C.PLAN_CLUSTER
+    assert _C.lib().ltr_linear_fused_plan(_C.HINGE, B, L, F) == (_C.PLAN_CLUSTER if which == "cluster" else _C.PLAN_PARTS)
     good = linear_loss_step(*args, loss="hinge")
     torch.cuda.synchronize()
     assert _C.lib().ltr_device_status(0) == 0
@@ -99,8 +189,13 @@ def test_cluster_wait_timeout_is_an_error_not_a_silent_nan():
         torch.cuda.synchronize()
     finally:
         lib.ltr_debug_force_timeout(0)
-    multi = n.numpy() > 0
-    assert np.all(np.isnan(loss.cpu().numpy()[multi])), "a failed wait must poison the loss"
+    if which == "cluster":
+        multi = n.numpy() > 0
+        assert np.all(np.isnan(loss.cpu().numpy()[multi])), "a failed wait must poison the loss"
+    else:
+        # (a workgroup is poisoned from its first failed wait on: at least the queries of several parts
+        # whose scores had not all arrived; single-part queries never wait)
+        assert np.any(np.isnan(loss.cpu().numpy())), "a failed wait must poison the loss"
     assert np.all(np.isnan(dW.cpu().numpy()))
     assert lib.ltr_device_status(0) == _C.ERR_TIMEOUT
     with pytest.raises(RuntimeError, match="gave up"):
