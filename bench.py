@@ -28,9 +28,11 @@ synchronize; it is repeated 5 times and the MEDIAN repeat is reported (max over 
 N > 1: one process per GPU, queries are independent units -> no data-path collective.  Weak
 scaling by default (every rank owns its own B queries per step); `--shard` splits BASELINE's global
 batch over the ranks instead (C4: 32 queries / GPU at N = 8).  The only exchange is the scorer
-gradient: each rank accumulates `--accum` (default 8) micro-batch steps into one bucket
-[dW (F) | db | loss_sum | count] in HBM (reduce kernel with accumulate) and all-reduces it ONCE per
-`accum` steps over RCCL -- gradient accumulation, stated in config.allreduce_every.
+gradient, ONE all-reduce PER STEP of the bucket [dW (F) | db | loss_sum] over RCCL (what north_star /
+SURVEY.md 8(e) specify; config.allreduce_every = 1): step i's all-reduce is enqueued
+by the C ABI behind the step's kernels (ltr_linear_step_f32 + pytorchltr_amd.distributed.RcclOverlap;
+the overlapped variants measured slower on this stack, see main()).  `--accum K` (K > 1) is the gradient-accumulation variant -- K micro-batch
+steps accumulated in HBM per all-reduce -- reported in `extra` at N > 1, never the headline.
 
 Prints ONE JSON line on rank 0 (metric, value, ..., roofline, cpu_baseline, extra).
 """
@@ -240,15 +242,23 @@ class FusedStep:
             batch["rel"].data_ptr(), self._C.LABEL_I64, batch["n"].data_ptr(), self.B, self.L, self.F,
             self.lossv.data_ptr(), None, self.part.data_ptr(), self._stream()))
 
-    def reduce(self, accumulate=False):
-        fp = self.flat.data_ptr()
+    def reduce(self, accumulate=False, flat=None):
+        fp = (self.flat if flat is None else flat).data_ptr()
         self._C.check(self.lib.ltr_linear_reduce_accum_f32(
             self.part.data_ptr(), self.go.data_ptr(), self.lossv.data_ptr(), self.B, self.F, fp,
             fp + 4 * self.F, fp + 4 * (self.F + 1), 1 if accumulate else 0, self._stream()))
 
-    def step(self, batch, accumulate=False):
+    def step(self, batch, accumulate=False, flat=None):
+        """The step in ONE C-ABI call (ltr_linear_step_f32 = partials + reduce into the bucket)."""
+        self._C.check(self.lib.ltr_linear_step_f32(
+            self.kind_id, 1.0, batch["X"].data_ptr(), self.W.data_ptr(), self.bias.data_ptr(),
+            batch["rel"].data_ptr(), self._C.LABEL_I64, batch["n"].data_ptr(), self.go.data_ptr(), self.B, self.L,
+            self.F, self.lossv.data_ptr(), (self.flat if flat is None else flat).data_ptr(), 1 if accumulate else 0,
+            self.part.data_ptr(), self.ws_bytes, None, 0, self._stream()))
+
+    def step_two_calls(self, batch, accumulate=False, flat=None):
         self.kernel(batch)
-        self.reduce(accumulate)
+        self.reduce(accumulate, flat)
 
 
 def pmc_record(workload):
@@ -464,6 +474,82 @@ def allreduce_probe():
         fs.step(batches[i % 2])
     torch.cuda.synchronize()
     out["step_without_allreduce_us"] = (time.perf_counter() - t0) / 800 * 1e6
+    # the N > 1 headline mode: one all-reduce per step, double-buffered and asynchronous
+    from pytorchltr_amd.distributed import OverlappedBucketAllReduce
+    red = OverlappedBucketAllReduce(F, count=B, device=dev)
+    for i in range(40):
+        fs.step(batches[i % 2], flat=red.acquire(i))
+        red.launch(i)
+    red.flush()
+    torch.cuda.synchronize()
+    reps = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for i in range(800):
+            fs.step(batches[i % 2], flat=red.acquire(i))
+            red.launch(i)
+        red.flush()
+        torch.cuda.synchronize()
+        reps.append((time.perf_counter() - t0) / 800 * 1e6)
+    out["step_with_overlapped_allreduce_every_1_us"] = sorted(reps)[1]
+    from pytorchltr_amd.distributed import RcclOverlap
+    from pytorchltr_amd import _C
+    for depth in (0, 4):
+        rawd = RcclOverlap(F, count=B, device=dev, depth=depth)
+        if rawd.ok:
+            def dstep(i):
+                b = batches[i % 2]
+                rawd.step(i, fs.kind_id, 1.0, b["X"], fs.W, fs.bias, b["rel"], _C.LABEL_I64, b["n"], fs.go, B, L, F,
+                          fs.lossv, fs.part)
+            for i in range(40):
+                dstep(i)
+            rawd.flush()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(800):
+                dstep(i)
+            t_host = time.perf_counter() - t0
+            rawd.flush()
+            torch.cuda.synchronize()
+            out["raw_rccl_depth%d_us" % depth] = (time.perf_counter() - t0) / 800 * 1e6
+            out["raw_rccl_depth%d_host_enqueue_us" % depth] = t_host / 800 * 1e6
+        rawd.close()
+    raw = RcclOverlap(F, count=B, device=dev)
+    out["raw_rccl_communicator"] = bool(raw.ok)
+    out["raw_rccl_note"] = raw.why
+    if raw.ok:
+        def rstep(i):
+            b = batches[i % 2]
+            raw.step(i, fs.kind_id, 1.0, b["X"], fs.W, fs.bias, b["rel"], _C.LABEL_I64, b["n"], fs.go, B, L, F,
+                     fs.lossv, fs.part)
+        for i in range(40):
+            rstep(i)
+        raw.flush()
+        torch.cuda.synchronize()
+        reps = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for i in range(800):
+                rstep(i)
+            raw.flush()
+            torch.cuda.synchronize()
+            reps.append((time.perf_counter() - t0) / 800 * 1e6)
+        out["step_with_raw_rccl_overlapped_allreduce_every_1_us"] = sorted(reps)[1]
+        # the result is the same as without the exchange at one rank
+        ref = fs.flat.clone()
+        fs.step(batches[0])
+        torch.cuda.synchronize()
+        rstep(0)
+        got = raw.result(0)
+        torch.cuda.synchronize()
+        out["raw_rccl_matches_local_step"] = bool(torch.equal(got[:F + 2], fs.flat[:F + 2]))
+    raw.close()
+    t0 = time.perf_counter()
+    for i in range(500):
+        w = dist.all_reduce(fs.flat, async_op=True)
+    w.wait()
+    torch.cuda.synchronize()
+    out["allreduce_async_host_call_us"] = (time.perf_counter() - t0) / 500 * 1e6
     dist.destroy_process_group()
     print(json.dumps(out))
 
@@ -476,8 +562,9 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--shard", action="store_true",
                     help="strong scaling: BASELINE's global batch split over the ranks (default: weak, B per rank)")
-    ap.add_argument("--accum", type=int, default=8,
-                    help="N > 1: micro-batch steps accumulated per gradient all-reduce")
+    ap.add_argument("--accum", type=int, default=1,
+                    help="N > 1: micro-batch steps accumulated per gradient all-reduce (1 = one overlapped "
+                         "all-reduce per step, the headline; > 1 = gradient-accumulation variant)")
     ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replay figures")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="only the headline step + roofline")
@@ -542,15 +629,56 @@ def main():
     accum = max(1, args.accum) if dist is not None else 1
 
     # ---- the timed step: fused scorer + loss forward, backward to dW/db, eager, through the C ABI ----
+    red = None
+    allreduce_impl = None
     if dist is None:
         def step(i):
             fs.step(batches[i % nbuf])
+    elif accum == 1:
+        # one all-reduce per step, overlapped: step i writes bucket i % 2, its all-reduce is enqueued
+        # asynchronously and runs under step i + 1; the compute stream waits for it only when the bucket
+        # comes round again
+        # ONE all-reduce per step, issued by the C ABI itself behind the step's kernels (ltr_linear_step_f32
+        # with an in-stream handle: one ncclAllReduce call on the step's stream, RCCL communicator of its
+        # own, no Python / c10d bookkeeping in the step).  Measured at one rank (extra.allreduce_probe_1rank):
+        # c10d blocking all_reduce 24-31 us per step, c10d async + double buffering 39-42 (its host call
+        # alone is 22 us), a side stream + events 32-34 (a wait on a just-recorded event costs the host
+        # 6.5 us on ROCm 7.2, twice per step, helper thread or not) -- against 14.9 in-stream, where the
+        # collective's own latency stays on the stream.
+        from pytorchltr_amd.distributed import OverlappedBucketAllReduce, RcclOverlap
+        mode = os.environ.get("LTR_BENCH_ALLREDUCE", "instream")
+        raw = RcclOverlap(F, count=B, device=dev, depth=(0 if mode == "instream" else 2)) if mode != "c10d" else None
+        if raw is not None and raw.ok:
+            red = raw
+            allreduce_impl = ("ltr_linear_step_f32 + %s handle: ncclAllReduce %s (RCCL communicator of its own)" % (
+                ("in-stream", "on the step's stream behind its kernels") if mode == "instream" else
+                ("overlap", "on a side stream under the next step")))
+
+            def step(i):
+                b = batches[i % nbuf]
+                raw.step(i, fs.kind_id, 1.0, b["X"], fs.W, fs.bias, b["rel"], _C.LABEL_I64, b["n"], fs.go, B, L, F,
+                         fs.lossv, fs.part)
+        else:
+            if raw is not None:
+                sys.stderr.write("[bench] raw RCCL communicator unavailable (%s): torch.distributed all_reduce\n" % raw.why)
+                raw.close()
+            red = OverlappedBucketAllReduce(F, count=B, device=dev, depth=1)
+            allreduce_impl = "torch.distributed all_reduce per step (blocking)"
+
+            def step(i):
+                flat = red.acquire(i)
+                fs.step(batches[i % nbuf], flat=flat)
+                red.launch(i)
+                red.result(i)
     else:
+        ar_view = fs.flat[:F + 2]                # (the count slot is not all-reduced again and again)
+        fs.flat[F + 2] = float(B * n_gpus)
+
         def step(i):
             j = i % accum
             fs.step(batches[i % nbuf], accumulate=(j != 0))
             if j == accum - 1:
-                dist.all_reduce(fs.flat, op=dist.ReduceOp.SUM)
+                dist.all_reduce(ar_view, op=dist.ReduceOp.SUM)
 
     for i in range(max(args.warmup, 2 * nbuf)):
         step(i)
@@ -573,12 +701,36 @@ def main():
         steps_timed = int(t.item())
     steps_timed = ((steps_timed + accum - 1) // accum) * accum
     regions = time_region(step, steps_timed, barrier, repeats=5, reduce_max=reduce_max)
+    if red is not None:
+        red.flush()
+        if hasattr(red, "close"):
+            red.close()
     elapsed = median(regions)
     value = n_gpus * B * steps_timed / elapsed
+
+    # N > 1, headline mode: the gradient-accumulation variant (one all-reduce per 8 steps) next to it
+    accum8 = None
+    if dist is not None and accum == 1:
+        ar_view = fs.flat[:F + 2]
+        fs.flat[F + 2] = float(B * n_gpus)
+
+        def step8(i):
+            j = i % 8
+            fs.step(batches[i % nbuf], accumulate=(j != 0))
+            if j == 7:
+                dist.all_reduce(ar_view, op=dist.ReduceOp.SUM)
+        n8 = max(8, (steps_timed // 2 // 8) * 8)
+        for i in range(16):
+            step8(i)
+        r8 = time_region(step8, n8, barrier, repeats=3, reduce_max=reduce_max)
+        accum8 = {"queries_per_s": n_gpus * B * n8 / median(r8), "ms_per_step": median(r8) / n8 * 1e3,
+                  "allreduce_every": 8, "what": "gradient accumulation: 8 micro-batch steps per all-reduce"}
 
     out = None
     if rank == 0:
         extra = {"timed_regions_s": regions, "steps_per_region": steps_timed}
+        if accum8 is not None:
+            extra["gradient_accumulation_8"] = accum8
         # ---- roofline of the dominant kernel: fused scorer+loss, cold, timed live with HIP events ----
         k_us, graphed = time_launches(lambda i: fs.kernel(batches[i % nbuf]), nbuf)
         k_evt = time_events(lambda i: fs.kernel(batches[i % nbuf]), 100)
@@ -604,6 +756,27 @@ def main():
                                "note": "SURVEY.md 8(d) bytes (padded rows counted although never read)"},
             "valu_issue_frac": valu_frac(pmc.get("valu_insts_per_launch"), k_us),
         }
+        # what ONE ROUND of workgroups can stream at this batch size: the same grid, workgroup size and
+        # ragged spans with nothing behind the loads (ltr_debug_stream_probe_f32)
+        if fs.plan == "linear_regtile_kernel" and L * (F // 4) <= 19 * 512 and F % 4 == 0:
+            pout = torch.empty(B * 8, device=dev)
+
+            def probe(i):
+                bt = batches[i % nbuf]
+                _C.check(_C.lib().ltr_debug_stream_probe_f32(bt["X"].data_ptr(), bt["n"].data_ptr(), B, L, F,
+                                                             pout.data_ptr(), torch.cuda.current_stream().cuda_stream))
+            for i in range(2 * nbuf):
+                probe(i)
+            p_us, _ = time_launches(probe, nbuf)
+            rows = sum(b_["rows"] for b_ in batches) / float(len(batches))
+            pbytes = rows * 4 * F + B * 8 + B * 32
+            roofline["launch_ceiling"] = {
+                "us": p_us, "bytes_per_launch": pbytes, "GBs": pbytes / (p_us * 1e-6) / 1e9,
+                "frac_of_peak": pbytes / (p_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "kernel_over_ceiling": k_us / p_us,
+                "what": "stream_probe_kernel: same grid (one 512-thread workgroup per query), same ragged spans, "
+                        "16-byte buffer loads all in flight, one dword store per wave -- no scores, no pair pass, "
+                        "no dW; cold, same rotating batches, same timing method"}
         if n_gpus == 1 and not args.full_lists and not args.no_extra:
             full_res, _, _ = measure_config(args.workload, B, L, F, kind, dev, 2000, full=True)
             roofline["full_lists"] = {k: full_res[k] for k in (
@@ -638,7 +811,10 @@ def main():
                        "mode": "eager", "parallelism": "dp%d" % n_gpus,
                        "batches_in_rotation": nbuf, "steps_timed": steps_timed, "repeats": 5,
                        "statistic": "median of 5 timed regions",
-                       "allreduce_every": accum if dist is not None else None},
+                       "allreduce_every": accum if dist is not None else None,
+                       "allreduce": (None if dist is None else
+                                     ("one per step: " + str(allreduce_impl) if accum == 1 else
+                                      "blocking, once per %d accumulated steps" % accum))},
             "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
         }
     barrier()

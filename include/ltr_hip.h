@@ -83,6 +83,11 @@ int ltr_max_list_len_f64(void);
 int ltr_device_status(int clear);
 /* Tests only: != 0 makes every in-launch wait of the cluster kernel give up at once. */
 void ltr_debug_force_timeout(int on);
+/* Measurement aid (bench.py `roofline.launch_ceiling`): the launch geometry of the register-tile kernel --
+ * one 512-thread workgroup per query, 16-byte buffer loads over the query's n[b] * F real floats, all in
+ * flight at once -- with no computation behind the loads: every wave stores one dword to out
+ * (B * 8 floats).  Shapes with L * F / 4 <= 19 * 512 vectors per query. */
+int ltr_debug_stream_probe_f32(const float *X, const int64_t *n, int B, int L, int F, float *out, void *stream);
 /* Tests / measurements only: which kernel layout ltr_mlp_pairwise_f32 takes where both apply.
  * 0 = automatic (the 4-wave tile kernel of csrc/ltr_mlp2.inc for batches of at least two queries per
  * CU-slot and for lists over 128 documents, else the 8-wave kernel of csrc/ltr_mlp.inc), 1 = the
@@ -281,6 +286,42 @@ int ltr_linear_reduce_loss_f32(const float *partials, const float *grad_out, con
 int ltr_linear_reduce_accum_f32(const float *partials, const float *grad_out, const float *loss,
                                 int B, int F, float *dW, float *db, float *loss_sum, int accumulate,
                                 void *stream);
+
+/* --- the whole training-step slice in ONE call, and its gradient exchange -------------------------
+ * ltr_linear_step_f32 = ltr_linear_partials_f32 + ltr_linear_reduce_accum_f32 behind one entry point:
+ * what `loss_fn(Linear(F,1)(xs), ys, n)` -> `.backward()` costs a host thread per step is one call
+ * instead of two (examples/01-basic-usage.py:66-75).  `bucket` is the step's flattened gradient
+ * bucket, F + 2 floats [dW (F) | db | loss_sum]: the unit a data-parallel job all-reduces
+ * (SURVEY.md section 8(e)); accumulate != 0 adds to it (gradient accumulation).
+ *
+ * With an overlap handle the call also runs the step's gradient all-reduce WITHOUT stalling the step
+ * (one process per GPU, RCCL over xGMI; pytorchltr_amd.distributed.RcclOverlap builds the handle):
+ *   1. `stream` waits for the all-reduce this slot's bucket was last given to (no host block),
+ *   2. the step's kernels are launched on `stream`,
+ *   3. an event is recorded behind them and the slot handed to the handle's helper thread, which makes
+ *      the handle's side stream wait for that event and enqueues
+ *      allreduce_fn(bucket, bucket, F + 2, ncclFloat32, ncclSum, comm, side_stream) -- it runs under the
+ *      NEXT step's kernels (the caller rotates `depth` buckets / slots), and the host cost of the
+ *      cross-stream dependency (6.5 us per wait on a just-recorded event on ROCm 7.2) is not on the
+ *      thread that launches the steps.
+ * depth = 0 makes an IN-STREAM handle: no side stream, no helper; the all-reduce is enqueued on `stream`
+ * right behind the step's kernels (one ncclAllReduce call of host cost, the collective's latency on the
+ * stream).
+ * allreduce_fn has ncclAllReduce's signature; the library does not link RCCL, the caller passes the
+ * function and the communicator (so the CPU-only build and the tests need no RCCL).
+ * ltr_overlap_wait makes a stream wait for a slot's pending all-reduce (before an optimiser reads the
+ * bucket), ltr_overlap_flush blocks the host until every pending all-reduce is done. */
+typedef int (*ltr_allreduce_fn)(const void *sendbuf, void *recvbuf, size_t count, int datatype, int op,
+                                void *comm, void *stream);
+int ltr_overlap_create(ltr_allreduce_fn allreduce_fn, void *comm, int depth, void **handle);
+int ltr_overlap_destroy(void *handle);
+int ltr_overlap_wait(void *handle, int slot, void *stream);
+int ltr_overlap_flush(void *handle);
+int ltr_linear_step_f32(int kind, float sigma, const float *X, const float *W, const float *bias,
+                        const void *rel, int rel_dtype, const int64_t *n, const float *grad_out,
+                        int B, int L, int F, float *loss, float *bucket /* F + 2 */, int accumulate,
+                        void *workspace, size_t workspace_bytes, void *overlap /* or NULL */, int slot,
+                        void *stream);
 
 /* --- fused ReLU-MLP scorer + loss + backward --------------------
  * Replaces the user-side composition `loss_fn(model(xs), ys, n)` + `.backward()` with `model` the

@@ -30,6 +30,7 @@ SIGNATURES = {
     "ltr_max_list_len_f64": (_i, []),
     "ltr_device_status": (_i, [_i]),
     "ltr_debug_force_timeout": (None, [_i]),
+    "ltr_debug_stream_probe_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ltr_debug_mlp_layout": (None, [_i]),
     "ltr_pairwise_loss_f32": (_i, [_i, _f, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "ltr_pairwise_loss_f32_cfg": (_i, [_i, _f, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
@@ -53,6 +54,12 @@ SIGNATURES = {
     "ltr_collate_pad_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ltr_linear_workspace_bytes": (_sz, [_i, _i, _i]),
     "ltr_linear_fused_plan": (_i, [_i, _i, _i, _i]),
+    "ltr_overlap_create": (_i, [_vp, _vp, _i, _vp]),
+    "ltr_overlap_destroy": (_i, [_vp]),
+    "ltr_overlap_wait": (_i, [_vp, _i, _vp]),
+    "ltr_overlap_flush": (_i, [_vp]),
+    "ltr_linear_step_f32": (_i, [_i, _f, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _sz,
+                                _vp, _i, _vp]),
     "ltr_linear_pairwise_f32": (_i, [_i, _f, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i,
                                      _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ltr_linear_partials_f32": (_i, [_i, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i,

@@ -46,7 +46,7 @@ def build_extension(force=False, verbose=False, extra_flags=(), lib_path=None):
     obj_dir = OBJ_DIR if lib_path == LIB_PATH else lib_path + ".obj"
     os.makedirs(obj_dir, exist_ok=True)
     common = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
-              "-Wall", "-Wno-unused-function", "-I", os.path.join(_ROOT, "include"), "-I", CSRC] + list(extra_flags)
+              "-pthread", "-Wall", "-Wno-unused-function", "-I", os.path.join(_ROOT, "include"), "-I", CSRC] + list(extra_flags)
     jobs = []
     for src in SOURCES:
         obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
@@ -59,7 +59,7 @@ def build_extension(force=False, verbose=False, extra_flags=(), lib_path=None):
         if proc.wait() != 0:
             raise subprocess.CalledProcessError(proc.returncode, cmd)
         objs.append(obj)
-    link = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc", "-o", lib_path] + objs
+    link = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc", "-pthread", "-o", lib_path] + objs
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.check_call(link)

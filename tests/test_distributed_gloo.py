@@ -142,3 +142,57 @@ def test_bench_bucket_layout_with_accumulation_two_ranks(tmp_path):
         assert float(db) == pytest.approx(want_db, rel=1e-5, abs=1e-6)
         assert float(lsum) == pytest.approx(want_loss, rel=1e-5)
         assert float(cnt) == world * B
+
+
+def _overlap_worker(rank, world, port, B, L, F, steps, out_dir):
+    """bench.py's N > 1 headline step on CPU: one all-reduce per step through the double-buffered,
+    asynchronous bucket, next to a plain blocking all-reduce of the same local values."""
+    import bench
+    from oracle import ltr_oracle as O
+    from pytorchltr_amd.distributed import OverlappedBucketAllReduce
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        Bl = B + rank                                                  # unequal shards: the count is summed once
+        red = OverlappedBucketAllReduce(F, count=Bl, device="cpu")
+        total = red.global_count
+        W0 = synth(B, L, 0, F=F)[4]
+        got, want = [], []
+        for i in range(steps):
+            s, y, n, X, W, b = synth(Bl, L, 1000 * rank + i, F=F)
+            go = np.full(Bl, 1.0 / total)
+            loss, _, gW, gb = O.linear_pairwise("logistic", X.numpy(), W0.numpy(), 0.25, y.numpy(), n.numpy(), go)
+            local = torch.tensor(np.r_[gW, gb, loss.sum()], dtype=torch.float32)
+            flat = red.acquire(i)                                      # (waits for step i - 2's collective)
+            dW, db, lsum, cnt = bench.bucket_views(flat, F)
+            dW.copy_(local[:F]); db.copy_(local[F:F + 1]); lsum.copy_(local[F + 1:F + 2])   # "the reduce kernel"
+            red.launch(i)
+            ref = local.clone()
+            dist.all_reduce(ref, op=dist.ReduceOp.SUM)                 # the un-overlapped exchange
+            want.append(ref.numpy().copy())
+            if i >= 1:
+                got.append(red.result(i - 1).numpy().copy())          # the optimiser reads step i - 1 here
+        got.append(red.result(steps - 1).numpy().copy())
+        red.flush()
+        np.savez(os.path.join(out_dir, "overlap%d.npz" % rank), got=np.array(got), want=np.array(want), total=total)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_bucket_equals_blocking_allreduce_two_ranks(tmp_path):
+    """The double-buffered asynchronous bucket gives, step for step, exactly what a blocking all-reduce
+    of the same local values gives (bit-identical: same collective, same operands), and the count slot
+    holds the global query count without being reduced again every step."""
+    B, L, F, steps, world = 5, 9, 4, 6, 2
+    port = _free_port()
+    mp.spawn(_overlap_worker, args=(world, port, B, L, F, steps, str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        z = np.load(os.path.join(str(tmp_path), "overlap%d.npz" % rank))
+        assert float(z["total"]) == 2 * B + 1
+        assert z["got"].shape == (steps, F + 3)
+        assert np.array_equal(z["got"][:, :F + 2], z["want"])
+        assert np.all(z["got"][:, F + 2] == 2 * B + 1)
+    a = np.load(os.path.join(str(tmp_path), "overlap0.npz"))["got"]
+    b = np.load(os.path.join(str(tmp_path), "overlap1.npz"))["got"]
+    assert np.array_equal(a, b)

@@ -68,6 +68,13 @@ def test_fused_step_c2_shape(kind):
     _check(kind, 16, 128, 136, 4, grad_out=torch.linspace(-0.5, 1.5, 16))
 
 
+@pytest.mark.parametrize("kind", ["hinge", "ndcg2"])
+def test_fused_step_c2_c3_full_lists_full_size(kind):
+    """The n == list_len twin of C2 / C3 at FULL size through the fused path (every row against the
+    oracle): the worst case for work, and the shape the roofline's `full_lists` figure is quoted on."""
+    _check(kind, 1024, 128, 136, 0, full=True)
+
+
 @pytest.mark.parametrize("shape", [(6, 1000, 220, "dcg_hinge"), (6, 512, 700, "hinge"),
                                    (4, 300, 64, "ndcg1"), (3, 2000, 16, "arp2")])
 def test_fused_step_large_tiles(shape):
