@@ -185,6 +185,21 @@ int ltr_dcg_tie_f32(const float *scores, const void *rel, int rel_dtype, const i
 int ltr_arp_tie_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n,
                     const int32_t *tie, int B, int L, float *out, void *stream);
 
+/* The same three with the tie words made IN the kernel from a seed -- no permutation is drawn or shipped:
+ * list position j gets the 31-bit word  hash19(seed, j) << 12 | j  (ltr_tie_hash_word; distinct for every
+ * j < 4096), and of two documents with equal masked score the smaller word ranks first: one pseudo-random
+ * permutation of the tied positions per call, shared by all rows, which is what tiebreak_argsort's
+ * `p = randperm(L)` is for (utils/tensor_operations.py:43-45).  `seed_dev` (device int64[1]) overrides
+ * `seed` when not NULL (a device generator's draw, no host round trip).  L <= 4096. */
+int ltr_rank_by_score_seed_f32(const float *scores, const int64_t *n, uint64_t seed, const int64_t *seed_dev,
+                               int B, int L, int64_t *ranking, void *stream);
+int ltr_dcg_seed_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n, uint64_t seed,
+                     const int64_t *seed_dev, int B, int L, int k, int use_exp, int normalize, float *out,
+                     void *stream);
+int ltr_arp_seed_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n, uint64_t seed,
+                     const int64_t *seed_dev, int B, int L, float *out, void *stream);
+uint32_t ltr_tie_hash_word(uint64_t seed, uint32_t position);     /* host helper: the word itself */
+
 /*
  * Listwise softmax cross-entropy (ListNet top-one; named by the project brief, ABSENT from the
  * reference: pytorchltr/loss/__init__.py:1-7 exports no such class -- parity unpinned, the

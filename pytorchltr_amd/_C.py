@@ -46,6 +46,10 @@ SIGNATURES = {
     "ltr_rank_by_score_tie_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "ltr_dcg_tie_f32": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ltr_arp_tie_f32": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    "ltr_rank_by_score_seed_f32": (_i, [_vp, _vp, ctypes.c_uint64, _vp, _i, _i, _vp, _vp]),
+    "ltr_dcg_seed_f32": (_i, [_vp, _vp, _i, _vp, ctypes.c_uint64, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ltr_arp_seed_f32": (_i, [_vp, _vp, _i, _vp, ctypes.c_uint64, _vp, _i, _i, _vp, _vp]),
+    "ltr_tie_hash_word": (ctypes.c_uint32, [ctypes.c_uint64, ctypes.c_uint32]),
     "ltr_listwise_softmax_f32": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "ltr_mask_padded_values_f32": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp]),
     "ltr_batch_pairs": (_i, [_vp, _i, _i, _i, _vp, _vp]),

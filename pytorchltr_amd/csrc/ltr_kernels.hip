@@ -413,6 +413,9 @@ struct MetricParams {
     const void *rel;
     const int64_t *n;
     const int32_t *tie;   // (L) tie priorities (a permutation of 0..L-1) or null = index order
+    unsigned long long tie_seed;   // use_seed: tie words hashed from (seed, position), see tie_hash_word
+    const int64_t *tie_seed_dev;   //   the seed read from device memory instead (a device generator's draw)
+    int use_seed;
     void *out;
     int B, L;
     int rel_dtype;
@@ -513,7 +516,10 @@ metric_kernel(MetricParams p)
         // random tie-break: the low key word is the document's tie priority; the inverse map
         // (priority -> document) sits behind the other arrays
         int *invt = nullptr;
-        if (p.tie) {
+        const unsigned long long seed = p.use_seed ? (p.tie_seed_dev ? (unsigned long long)p.tie_seed_dev[0] : p.tie_seed) : 0ull;
+        const int low_mask = p.use_seed ? 0xFFF : 0;
+        auto tie_word = [&](int i) { return p.use_seed ? (int)tie_hash_word(seed, (unsigned)i) : (p.tie ? p.tie[i] : i); };
+        if (p.tie && !p.use_seed) {
             invt = reinterpret_cast<int *>(smem + metric_lds_bytes_sort(L) - 4 * (size_t)L4);
             for (int j = tid; j < L; j += T) invt[p.tie[j]] = j;
             __syncthreads();
@@ -522,23 +528,25 @@ metric_kernel(MetricParams p)
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int i = e * T + tid;
-            v[e] = (i < nb) ? rank_key(sy[i].x, p.tie ? p.tie[i] : i) : ~0ull;
+            v[e] = (i < nb) ? rank_key(sy[i].x, tie_word(i)) : ~0ull;
         }
-        sort_ranks<E>(v, Pq, nb, rank_s, xbuf, invt);
+        sort_ranks<E>(v, Pq, nb, rank_s, xbuf, invt, low_mask);
         if (with_y) {
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const int i = e * T + tid;
-                v[e] = (i < nb) ? rank_key(sy[i].y, p.tie ? p.tie[i] : i) : ~0ull;
+                v[e] = (i < nb) ? rank_key(sy[i].y, tie_word(i)) : ~0ull;
             }
-            sort_ranks<E>(v, Pq, nb, rank_y, xbuf, invt);
+            sort_ranks<E>(v, Pq, nb, rank_y, xbuf, invt, low_mask);
         }
     } else {
         // counting rank on packed keys (see count_ranks_keyed); the keys live in the curve region
         ulonglong2 *keys = reinterpret_cast<ulonglong2 *>(curve);
         for (int k = tid; k < nb; k += T) {
             const float2 v = sy[k];
-            const int t = p.tie ? p.tie[k] : k;         // tie priority (random tie-break) or index
+            // tie word: hashed from the seed, a caller-drawn priority, or the index
+            const int t = p.use_seed ? (int)tie_hash_word(p.tie_seed_dev ? (unsigned long long)p.tie_seed_dev[0] : p.tie_seed, (unsigned)k)
+                                     : (p.tie ? p.tie[k] : k);
             keys[k] = make_ulonglong2(rank_key(v.x, t), rank_key(v.y, t));
         }
         __syncthreads();
@@ -1177,6 +1185,56 @@ int ltr_arp_f32(const float *scores, const void *rel, int rel_dtype, const int64
     LTR_CLEAR_STALE_ERROR();
     return ltr_arp_tie_f32(scores, rel, rel_dtype, n, nullptr, B, L, out, stream);
 }
+
+// ---- the same three with the tie words hashed in the kernel from a seed (see tie_hash_word) ----
+int ltr_rank_by_score_seed_f32(const float *scores, const int64_t *n, uint64_t seed, const int64_t *seed_dev,
+                               int B, int L, int64_t *ranking, void *stream)
+{
+    LTR_CLEAR_STALE_ERROR();
+    if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
+    if (L > kMaxListLen || L > kTieHashMaxLen) return LTR_ERR_LIST_TOO_LONG;
+    if (B == 0) return LTR_OK;
+    if (!scores || !n || !ranking) return LTR_ERR_NULL;
+    MetricParams p{};
+    p.scores = scores; p.rel = nullptr; p.n = n; p.tie = nullptr; p.out = ranking; p.B = B; p.L = L;
+    p.use_seed = 1; p.tie_seed = seed; p.tie_seed_dev = seed_dev;
+    return launch_metric<METRIC_RANK>(p, (hipStream_t)stream);
+}
+
+int ltr_dcg_seed_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n, uint64_t seed,
+                     const int64_t *seed_dev, int B, int L, int k, int use_exp, int normalize, float *out,
+                     void *stream)
+{
+    LTR_CLEAR_STALE_ERROR();
+    if (bad_label_dtype(rel_dtype)) return LTR_ERR_KIND;
+    if (B < 0 || L <= 0 || k < 0) return LTR_ERR_SHAPE;
+    if (L > kMaxListLen || L > kTieHashMaxLen) return LTR_ERR_LIST_TOO_LONG;
+    if (B == 0) return LTR_OK;
+    if (!scores || !rel || !n || !out) return LTR_ERR_NULL;
+    MetricParams p{};
+    p.scores = scores; p.rel = rel; p.n = n; p.tie = nullptr; p.out = out; p.B = B; p.L = L;
+    p.rel_dtype = rel_dtype; p.k = k; p.use_exp = use_exp; p.normalize = normalize;
+    p.use_seed = 1; p.tie_seed = seed; p.tie_seed_dev = seed_dev;
+    return launch_metric<METRIC_DCG>(p, (hipStream_t)stream);
+}
+
+int ltr_arp_seed_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n, uint64_t seed,
+                     const int64_t *seed_dev, int B, int L, float *out, void *stream)
+{
+    LTR_CLEAR_STALE_ERROR();
+    if (bad_label_dtype(rel_dtype)) return LTR_ERR_KIND;
+    if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
+    if (L > kMaxListLen || L > kTieHashMaxLen) return LTR_ERR_LIST_TOO_LONG;
+    if (B == 0) return LTR_OK;
+    if (!scores || !rel || !n || !out) return LTR_ERR_NULL;
+    MetricParams p{};
+    p.scores = scores; p.rel = rel; p.n = n; p.tie = nullptr; p.out = out; p.B = B; p.L = L;
+    p.rel_dtype = rel_dtype;
+    p.use_seed = 1; p.tie_seed = seed; p.tie_seed_dev = seed_dev;
+    return launch_metric<METRIC_ARP>(p, (hipStream_t)stream);
+}
+
+uint32_t ltr_tie_hash_word(uint64_t seed, uint32_t position) { return tie_hash_word(seed, position); }
 
 int ltr_listwise_softmax_f32(const float *scores, const void *rel, int rel_dtype, const int64_t *n,
                              int B, int L, float *loss, float *dscores, void *stream)

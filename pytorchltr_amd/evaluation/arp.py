@@ -22,8 +22,12 @@ def arp(scores: _torch.FloatTensor, relevance: _torch.LongTensor,
     B, L = s.shape
     out = _torch.empty(B, dtype=_torch.float32, device=s.device)
     if B > 0:
-        tie = _ties.draw_priorities(L, s.device)      # random tie-break, as the reference (arp.py:32)
+        sd = _ties.draw_seed(L, s.device)             # random tie-break, as the reference (arp.py:32)
         with _C.device_ctx(s):
-            _C.check(_C.lib().ltr_arp_tie_f32(_C.ptr(s), _C.ptr(r), _C.label_dtype(r), _C.ptr(nn),
-                                              _C.ptr(tie), B, L, _C.ptr(out), _C.stream_of(s)))
+            if sd is None:
+                _C.check(_C.lib().ltr_arp_f32(_C.ptr(s), _C.ptr(r), _C.label_dtype(r), _C.ptr(nn), B, L,
+                                              _C.ptr(out), _C.stream_of(s)))
+            else:
+                _C.check(_C.lib().ltr_arp_seed_f32(_C.ptr(s), _C.ptr(r), _C.label_dtype(r), _C.ptr(nn), sd[0],
+                                                   _C.ptr(sd[1]), B, L, _C.ptr(out), _C.stream_of(s)))
     return out

@@ -33,11 +33,16 @@ def _run(scores, relevance, n, k, exp, normalize):
     out = _torch.empty((B,) if kk > 0 else (B, L), dtype=_torch.float32, device=s.device)
     if B > 0:
         # the reference ranks through rank_by_score with its global-RNG tie-break (dcg.py:85)
-        tie = _ties.draw_priorities(L, s.device)
+        # (round 3: a seed drawn on the host, hashed into tie words inside the kernel -- no randperm launches)
+        sd = _ties.draw_seed(L, s.device)
         with _C.device_ctx(s):
-            _C.check(_C.lib().ltr_dcg_tie_f32(_C.ptr(s), _C.ptr(r), _C.label_dtype(r), _C.ptr(nn),
-                                              _C.ptr(tie), B, L, kk, int(bool(exp)), int(normalize),
-                                              _C.ptr(out), _C.stream_of(s)))
+            if sd is None:
+                _C.check(_C.lib().ltr_dcg_f32(_C.ptr(s), _C.ptr(r), _C.label_dtype(r), _C.ptr(nn), B, L, kk,
+                                              int(bool(exp)), int(normalize), _C.ptr(out), _C.stream_of(s)))
+            else:
+                _C.check(_C.lib().ltr_dcg_seed_f32(_C.ptr(s), _C.ptr(r), _C.label_dtype(r), _C.ptr(nn), sd[0],
+                                                   _C.ptr(sd[1]), B, L, kk, int(bool(exp)), int(normalize),
+                                                   _C.ptr(out), _C.stream_of(s)))
     return out
 
 

@@ -46,14 +46,19 @@ def mask_padded_values(xs: _torch.FloatTensor, n: _torch.LongTensor,
     return out if xs.dtype == _torch.float32 else out.to(xs.dtype)
 
 
-def _rank(scores2d, nn, tie=None):
+def _rank(scores2d, nn, seed=None):
+    """seed: None (index order) or (seed, seed_tensor) from _ties.draw_seed."""
     B, L = scores2d.shape
     ranking = _torch.empty(B, L, dtype=_torch.int64, device=scores2d.device)
     if B > 0:
         with _C.device_ctx(scores2d):
-            _C.check(_C.lib().ltr_rank_by_score_tie_f32(
-                _C.ptr(scores2d), _C.ptr(nn), _C.ptr(tie), B, L, _C.ptr(ranking),
-                _C.stream_of(scores2d)))
+            if seed is None:
+                _C.check(_C.lib().ltr_rank_by_score_f32(
+                    _C.ptr(scores2d), _C.ptr(nn), B, L, _C.ptr(ranking), _C.stream_of(scores2d)))
+            else:
+                _C.check(_C.lib().ltr_rank_by_score_seed_f32(
+                    _C.ptr(scores2d), _C.ptr(nn), seed[0], _C.ptr(seed[1]), B, L, _C.ptr(ranking),
+                    _C.stream_of(scores2d)))
     return ranking
 
 
@@ -71,7 +76,7 @@ def tiebreak_argsort(
     if not descending:
         s = -s
     nn = _torch.full((s.shape[0],), s.shape[1], dtype=_torch.int64, device=s.device)
-    return _rank(s, nn, _ties.draw_priorities(s.shape[1], s.device, generator))
+    return _rank(s, nn, _ties.draw_seed(s.shape[1], s.device, generator))
 
 
 def rank_by_score(
@@ -86,7 +91,7 @@ def rank_by_score(
     max_l = _C.max_list_len()
     if s.shape[1] > max_l:
         raise ValueError("list_size %d exceeds the supported maximum %d" % (s.shape[1], max_l))
-    return _rank(s, nn, _ties.draw_priorities(s.shape[1], s.device, generator))
+    return _rank(s, nn, _ties.draw_seed(s.shape[1], s.device, generator))
 
 
 def _plackettluce_from_uniform(scores, n, uniform):

@@ -39,7 +39,12 @@ def test_mode_switch_and_draw():
         with tie_breaking("index"):
             assert get_tie_breaking() == "index"
             assert _ties.draw_priorities(8, torch.device("cpu")) is None
+            assert _ties.draw_seed(8, torch.device("cpu")) is None
         assert get_tie_breaking() == "random"
+        sd = _ties.draw_seed(8, torch.device("cpu"))
+        assert isinstance(sd[0], int) and 0 <= sd[0] < 2 ** 62 and sd[1] is None
+        ga, gb = torch.Generator().manual_seed(9), torch.Generator().manual_seed(9)
+        assert _ties.draw_seed(8, torch.device("cpu"), ga) == _ties.draw_seed(8, torch.device("cpu"), gb)
         p = _ties.draw_priorities(8, torch.device("cpu"))
         assert p.dtype == torch.int32 and sorted(p.tolist()) == list(range(8))
         g1 = torch.Generator().manual_seed(3)
@@ -84,6 +89,60 @@ def test_rank_and_metrics_with_priorities_match_oracle(L):
     # and without priorities: the index rule of the plain entry points
     _C.check(lib.ltr_rank_by_score_tie_f32(sd.data_ptr(), nd.data_ptr(), None, B, L, ranking.data_ptr(), st))
     assert np.array_equal(ranking.cpu().numpy(), O.rank_by_score(s.numpy(), n.numpy()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L", [7, 64, 100, 256, 300, 1000, 2500, 4096])
+def test_seeded_tie_words_match_oracle(L):
+    """Round 3: the tie words are hashed in the kernel from a seed (ltr_*_seed_f32, no permutation drawn
+    or shipped).  The oracle is given the SAME words (ltr_tie_hash_word on the host) as priorities and must
+    agree bit for bit on tie-heavy rows -- counting path and sort path, host seed and device seed."""
+    from pytorchltr_amd import _C, _ties
+    dev = torch.device("cuda:0")
+    B = 6
+    s, y, n, _ = _tie_heavy(B, L, 1000 + L)
+    sd, yd, nd = s.to(dev), y.to(dev), n.to(dev)
+    lib = _C.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    seed = 0x1234_5678_9ABC_DEF0 + L
+    words = _ties.hash_words(seed, L)
+    assert len(set(words.tolist())) == L and int(words.min()) >= 0          # distinct, non-negative int32
+    assert np.array_equal(words & 0xFFF, np.arange(L))                       # the position rides in the low bits
+    y0 = (y * (torch.arange(L)[None, :] < n[:, None])).to(dev)
+    with O.tie_priorities(words):
+        want_rank = O.rank_by_score(s.numpy(), n.numpy())
+        want_ndcg = O.ndcg(s.numpy(), y.numpy(), n.numpy(), k=10)
+        want_arp = O.arp(s.numpy(), y0.cpu().numpy(), n.numpy())
+    seed_dev = torch.tensor([seed], dtype=torch.int64, device=dev)
+    for host_seed, dptr in ((seed, None), (0, seed_dev.data_ptr())):
+        ranking = torch.empty(B, L, dtype=torch.int64, device=dev)
+        _C.check(lib.ltr_rank_by_score_seed_f32(sd.data_ptr(), nd.data_ptr(), host_seed, dptr, B, L,
+                                                ranking.data_ptr(), st))
+        out_ndcg = torch.empty(B, device=dev)
+        _C.check(lib.ltr_dcg_seed_f32(sd.data_ptr(), yd.data_ptr(), _C.LABEL_I64, nd.data_ptr(), host_seed, dptr,
+                                      B, L, 10, 1, 1, out_ndcg.data_ptr(), st))
+        out_arp = torch.empty(B, device=dev)
+        _C.check(lib.ltr_arp_seed_f32(sd.data_ptr(), y0.data_ptr(), _C.LABEL_I64, nd.data_ptr(), host_seed, dptr,
+                                      B, L, out_arp.data_ptr(), st))
+        assert np.array_equal(ranking.cpu().numpy(), want_rank)                  # bit-exact, ties included
+        assert np.allclose(out_ndcg.cpu().numpy(), want_ndcg, rtol=2e-5, atol=1e-6)
+        assert np.allclose(out_arp.cpu().numpy(), want_arp, rtol=2e-5, atol=1e-6)
+    # a different seed orders the ties differently
+    r2 = torch.empty(B, L, dtype=torch.int64, device=dev)
+    _C.check(lib.ltr_rank_by_score_seed_f32(sd.data_ptr(), nd.data_ptr(), seed + 1, None, B, L, r2.data_ptr(), st))
+    if L >= 64:
+        assert not np.array_equal(r2.cpu().numpy(), want_rank)
+
+
+def test_hashed_tie_words_spread_the_ties_evenly():
+    """The order of tied positions under the hash is close to a uniform random permutation: over many
+    seeds every position of a small list comes first about equally often."""
+    from pytorchltr_amd import _ties
+    L, trials = 8, 4000
+    first = np.zeros(L)
+    for t in range(trials):
+        first[int(np.argmin(_ties.hash_words(0x9E3779B97F4A7C15 * (t + 1) & (2 ** 62 - 1), L)))] += 1
+    assert np.all(np.abs(first / trials - 1.0 / L) < 0.03)
 
 
 @pytest.mark.gpu
