@@ -902,14 +902,17 @@ def n1_extras(args, kind, B, L, F, dev, batches, steps_timed):
         loss_fn(lin(b0["X"]), b0["rel"], b0["n"]).mean().backward()
     extra["dropin_linear_plus_loss_module"] = measure(dropin_step)
 
-    # (b2) the same user code with the package's streaming scorer in place of nn.Linear
-    scorer = LinearScorer(F).to(dev)
+    # (b2) the same user code after the one-liner `model = use_linear_scorer(model)`: the nn.Linear(F, 1)
+    # scorer swapped for the package's streaming scorer, parameters shared
+    from pytorchltr_amd.fused import use_linear_scorer
+    scorer = use_linear_scorer(torch.nn.Linear(F, 1).to(dev))
+    assert isinstance(scorer, LinearScorer)
 
     def dropin_scorer_step():
         scorer.weight.grad = None
         scorer.bias.grad = None
-        loss_fn(scorer(b0["X"], b0["n"]), b0["rel"], b0["n"]).mean().backward()
-    extra["dropin_linearscorer_plus_loss_module"] = measure(dropin_scorer_step)
+        loss_fn(scorer(b0["X"]), b0["rel"], b0["n"]).mean().backward()
+    extra["dropin_use_linear_scorer_plus_loss_module"] = measure(dropin_scorer_step)
 
     # (c) loss only (the literal "loss fwd+bwd" on precomputed scores), reference call signature
     sc = b0["scores"].clone().requires_grad_(True)

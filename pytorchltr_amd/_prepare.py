@@ -56,14 +56,14 @@ def prepare_n(n, batch):
     return n.contiguous()
 
 
-def prepare(scores, relevance, n, allow_f64=False):
+def prepare(scores, relevance, n, allow_f64=False, limit_len=True):
     s = prepare_scores(scores) if allow_f64 else prepare_scores_f32(scores)
     r = prepare_relevance(relevance, s)
     nn = prepare_n(n, s.shape[0])
     if not (s.device == r.device == nn.device):
         raise RuntimeError("scores, relevance and n must be on the same device")
     max_l = _C.max_list_len()
-    if s.shape[1] > max_l:
+    if limit_len and s.shape[1] > max_l:
         raise ValueError("list_size %d exceeds the supported maximum %d" % (s.shape[1], max_l))
     if s.shape[1] == 0:
         raise ValueError("list_size must be positive")

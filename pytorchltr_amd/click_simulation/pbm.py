@@ -15,6 +15,17 @@ from pytorchltr_amd import _C
 from pytorchltr_amd._prepare import prepare_n as _prepare_n
 
 _SIM_RETURN_TYPE = Tuple[_torch.LongTensor, _torch.FloatTensor]
+_validate = True
+
+
+def set_index_validation(on):
+    """Switches the per-call index check of the click simulators (labels index `relevance_probs`, rankings
+    index the list) on or off; returns the previous setting.  Off: no host-device synchronisation in
+    simulate_pbm and friends (out-of-range indices then read clamped entries instead of raising)."""
+    global _validate
+    prev, _validate = _validate, bool(on)
+    return prev
+
 
 
 def _simulate_pbm_from_uniform(rankings, ys, n, relevance_probs, uniform, cutoff, eta):
@@ -25,8 +36,10 @@ def _simulate_pbm_from_uniform(rankings, ys, n, relevance_probs, uniform, cutoff
     yy = ys.reshape(B, L).to(_torch.int64).contiguous()
     nn = _prepare_n(n, B)
     probs = relevance_probs.to(device=rk.device, dtype=_torch.float32).contiguous()
-    if B > 0 and L > 0:
-        # the reference's gathers raise on bad indices; one combined device-side check here
+    if B > 0 and L > 0 and _validate and not _torch.cuda.is_current_stream_capturing():
+        # the reference's gathers raise on bad indices; one combined device-side check here.  It costs a
+        # host-device synchronisation per call: `set_index_validation(False)` drops it, and it is
+        # skipped under stream capture, where a synchronisation is not allowed
         bad = ((yy < 0) | (yy >= probs.numel())).any() | ((rk < 0) | (rk >= L)).any()
         if bool(bad):
             raise IndexError("simulate_pbm: labels must index relevance_probs (%d entries) and rankings "

@@ -249,7 +249,12 @@ class _LinearScoreFunction(torch.autograd.Function):
             with _C.device_ctx(X):
                 _C.check(_C.lib().ltr_linear_scores_f32(_C.ptr(X), _C.ptr(W), _C.ptr(bvec), _C.ptr(nn),
                                                         B, L, F, _C.ptr(scores), _C.stream_of(X)))
-        ctx.save_for_backward(X, nn if nn is not None else torch.empty(0, device=X.device))
+        # (the layer's input needs a gradient only when it is not the feature batch itself -- a hidden
+        # layer's output: the weight is kept for grad_xs = grad_scores (x) weight in that case)
+        ctx.xs_grad = bool(torch.is_tensor(xs) and xs.requires_grad)
+        ctx.save_for_backward(X, nn if nn is not None else torch.empty(0, device=X.device),
+                              W if ctx.xs_grad else torch.empty(0, device=X.device))
+        ctx.xs_shape = xs.shape
         ctx.has_n = nn is not None
         ctx.w_shape = weight.shape
         ctx.has_bias = bias is not None
@@ -258,7 +263,7 @@ class _LinearScoreFunction(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_scores):
-        X, nn = ctx.saved_tensors
+        X, nn, Wsaved = ctx.saved_tensors
         B, L, F = X.shape
         g = grad_scores.reshape(B, L).float().contiguous()
         lib = _C.lib()
@@ -268,14 +273,21 @@ class _LinearScoreFunction(torch.autograd.Function):
         with _C.device_ctx(X):
             _C.check(lib.ltr_linear_grad_f32(_C.ptr(X), _C.ptr(g), _C.ptr(nn) if ctx.has_n else None,
                                              B, L, F, _C.ptr(out), _C.ptr(ws), ws_bytes, _C.stream_of(X)))
-        return (None, out[:F].reshape(ctx.w_shape), out[F:] if ctx.has_bias else None, None)
+        gx = None
+        if ctx.xs_grad:
+            gm = g
+            if ctx.has_n:                                       # padded documents were not scored
+                gm = g * (torch.arange(L, device=g.device)[None, :] < nn[:, None])
+            gx = (gm.unsqueeze(-1) * Wsaved.reshape(1, 1, F)).reshape(ctx.xs_shape)
+        return (gx, out[:F].reshape(ctx.w_shape), out[F:] if ctx.has_bias else None, None)
 
 
 class LinearScorer(torch.nn.Module):
     """``torch.nn.Linear(in_features, 1)`` for (B, L, F) feature batches, state_dict-compatible
     with it, computed by two HBM-streaming kernels instead of rocBLAS' one-column GEMM:
     ``loss_fn(scorer(xs), ys, n)`` is the reference's user code unchanged.  ``scorer(xs, n)`` also
-    skips the padded documents (score 0).  No gradient flows to ``xs`` (features are data)."""
+    skips the padded documents (score 0).  The feature batch gets no gradient (it is data); an input
+    that requires one (the layer sits behind others) gets ``grad_scores (x) weight``."""
 
     def __init__(self, in_features, bias=True):
         super().__init__()
@@ -289,6 +301,35 @@ class LinearScorer(torch.nn.Module):
 
     def forward(self, xs, n=None):
         return _LinearScoreFunction.apply(xs, self.weight, self.bias, n)
+
+
+def use_linear_scorer(model):
+    """The one-liner for an existing training script: every ``torch.nn.Linear(F, 1)`` inside `model`
+    (or `model` itself) is replaced by a :class:`LinearScorer` that SHARES its parameters -- same
+    ``state_dict`` keys, same Parameter objects, so optimisers, checkpoints and ``model.parameters()``
+    are unaffected -- and `loss_fn(model(xs), ys, n).mean().backward()` stops paying rocBLAS for a
+    one-column GEMM (304 us -> 46 us per step at the C2 shape; reference user code:
+    examples/01-basic-usage.py:36,66-75).  Returns the model (a new module when `model` itself was the
+    Linear layer).  Only applied where the layer's input is the (B, L, F) feature batch, i.e. where the
+    user wrote ``Linear(F, 1)`` as the scorer."""
+    def convert(lin):
+        sc = LinearScorer(lin.in_features, bias=lin.bias is not None)
+        sc.weight = lin.weight                      # the same Parameter objects
+        if lin.bias is not None:
+            sc.bias = lin.bias
+        return sc
+
+    def is_scorer(m):
+        return isinstance(m, torch.nn.Linear) and m.out_features == 1
+
+    if is_scorer(model):
+        return convert(model)
+    for name, child in list(model.named_children()):
+        if is_scorer(child):
+            setattr(model, name, convert(child))
+        else:
+            use_linear_scorer(child)
+    return model
 
 
 # ---------------------------------------------------------------------------------------------

@@ -9,9 +9,39 @@ implementation to pin it to**; the specification is ``include/ltr_hip.h``
 finite differences.
 """
 import torch as _torch
+from torch.autograd.function import once_differentiable as _once
 
-from pytorchltr_amd._autograd import LISTWISE_SOFTMAX as _LISTWISE_SOFTMAX
-from pytorchltr_amd._autograd import pairwise_loss as _loss
+from pytorchltr_amd import _C
+from pytorchltr_amd._prepare import prepare as _prepare
+
+
+class _ListwiseSoftmaxFunction(_torch.autograd.Function):
+    """Its own small Function: the pairwise plumbing does not apply -- the kernel has no
+    LDS-bound list limit (one wave walks the list), and it computes in fp32 whatever the score dtype
+    (fp64 / half scores are cast in and the result cast back, gradients included)."""
+
+    @staticmethod
+    def forward(ctx, scores, relevance, n):
+        s, r, nn = _prepare(scores, relevance, n, allow_f64=False, limit_len=False)
+        B, L = s.shape
+        need_grad = ctx.needs_input_grad[0]
+        loss = _torch.empty(B, dtype=_torch.float32, device=s.device)
+        ds = _torch.empty(B, L, dtype=_torch.float32, device=s.device) if need_grad else None
+        if B > 0:
+            with _C.device_ctx(s):
+                _C.check(_C.lib().ltr_listwise_softmax_f32(_C.ptr(s), _C.ptr(r), _C.label_dtype(r), _C.ptr(nn), B, L,
+                                                           _C.ptr(loss), _C.ptr(ds), _C.stream_of(s)))
+        if need_grad:
+            ctx.save_for_backward(ds)
+        ctx.in_shape, ctx.in_dtype = scores.shape, scores.dtype
+        return loss if scores.dtype is _torch.float32 else loss.to(scores.dtype)
+
+    @staticmethod
+    @_once
+    def backward(ctx, grad_out):
+        (ds,) = ctx.saved_tensors
+        out = ds * grad_out.reshape(-1, 1).to(ds.dtype)
+        return out.reshape(ctx.in_shape).to(ctx.in_dtype), None, None
 
 
 class ListwiseSoftmaxLoss(_torch.nn.Module):
@@ -35,7 +65,7 @@ class ListwiseSoftmaxLoss(_torch.nn.Module):
 
     def forward(self, scores: _torch.FloatTensor, relevance: _torch.LongTensor,
                 n: _torch.LongTensor) -> _torch.FloatTensor:
-        return _loss(scores, relevance, n, _LISTWISE_SOFTMAX, 1.0)
+        return _ListwiseSoftmaxFunction.apply(scores, relevance, n)
 
 
 ListNetLoss = ListwiseSoftmaxLoss

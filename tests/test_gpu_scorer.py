@@ -110,3 +110,51 @@ def test_fused_linear_loss_takes_the_pieces_for_a_few_long_lists():
     assert np.allclose(loss.detach().cpu().numpy()[:3], want_l, rtol=5e-4, atol=1e-5)
     valid = np.arange(L)[None, :] < n[:3].numpy()[:, None]
     assert np.allclose(scores.cpu().numpy()[:3][valid], want_s[valid], rtol=1e-5, atol=1e-5)
+
+
+def test_use_linear_scorer_swaps_the_layer_and_keeps_the_parameters():
+    """the one-liner for an existing script.  nn.Linear(F, 1) scorers inside a model are
+    replaced by LinearScorer modules that SHARE the parameters (same state_dict, same optimiser state);
+    the training step gives the same gradients as the untouched model."""
+    import torch
+    from pytorchltr_amd.fused import LinearScorer, use_linear_scorer
+    from pytorchltr_amd.loss import PairwiseHingeLoss
+    dev = torch.device("cuda:0")
+    from tests.conftest import synth
+    s, y, n, X, W, b = synth(12, 40, 3, F=24)
+    X, y, n = X.to(dev), y.to(dev), n.to(dev)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.body = torch.nn.Sequential(torch.nn.Linear(24, 16), torch.nn.ReLU())
+            self.head = torch.nn.Linear(16, 1)
+
+        def forward(self, xs):
+            return self.head(self.body(xs))
+
+    torch.manual_seed(0)
+    ref = Net().to(dev)
+    torch.manual_seed(0)
+    net = Net().to(dev)
+    keys = list(net.state_dict().keys())
+    head_w = net.head.weight
+    use_linear_scorer(net)
+    assert isinstance(net.head, LinearScorer) and isinstance(net.body[0], torch.nn.Linear)
+    assert net.head.weight is head_w and list(net.state_dict().keys()) == keys
+    loss_fn = PairwiseHingeLoss()
+    loss_fn(ref(X), y, n).mean().backward()
+    loss_fn(net(X), y, n).mean().backward()                       # the hidden layer needs grad_xs from the scorer
+    for (ka, pa), (kb, pb) in zip(ref.named_parameters(), net.named_parameters()):
+        assert ka == kb
+        assert torch.allclose(pa.grad, pb.grad, rtol=1e-4, atol=2e-5), ka      # (d/d bias is a sum of +-1s that cancels: rounding noise)
+    # the plain case: the model IS the Linear(F, 1) of examples/01-basic-usage.py
+    lin = torch.nn.Linear(24, 1).to(dev)
+    sc = use_linear_scorer(lin)
+    assert isinstance(sc, LinearScorer) and sc.weight is lin.weight and sc.bias is lin.bias
+    loss_fn(sc(X), y, n).mean().backward()
+    g1 = lin.weight.grad.clone()
+    lin.weight.grad = None
+    lin.bias.grad = None
+    loss_fn(lin(X), y, n).mean().backward()
+    assert torch.allclose(g1, lin.weight.grad, rtol=1e-4, atol=1e-6)

@@ -97,3 +97,26 @@ def test_module_autograd_mean_and_sum():
         ListwiseSoftmaxLoss()(sc, y.to(dev), n.to(dev)).sum().backward()      # expanded-scalar gradient
         assert np.allclose(sc.grad.cpu().numpy().reshape(B, L), want_d, rtol=1e-5, atol=1e-6)
     assert np.allclose(loss.detach().cpu().numpy(), want_l, rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_listwise_loss_takes_fp64_scores_and_long_lists():
+    """its own autograd Function -- fp64 scores are computed in fp32 and cast back (the seven
+    reference losses accept fp64 too), and lists beyond the pairwise kernels' limit are fine (one wave
+    walks the list)."""
+    from pytorchltr_amd import _C
+    from pytorchltr_amd.loss import ListwiseSoftmaxLoss
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    L = _C.max_list_len() + 500
+    s = torch.randn(3, L, generator=g, dtype=torch.float64)
+    y = torch.randint(0, 5, (3, L), generator=g)
+    n = torch.tensor([L, 17, 0])
+    sd = s.to(dev).requires_grad_(True)
+    out = ListwiseSoftmaxLoss()(sd, y.to(dev), n.to(dev))
+    assert out.dtype == torch.float64
+    out.sum().backward()
+    assert sd.grad.dtype == torch.float64 and sd.grad.shape == (3, L)
+    want_l, want_g = O.listwise_softmax(s.numpy(), y.numpy(), n.numpy())
+    assert np.allclose(out.detach().cpu().numpy(), want_l, rtol=1e-5, atol=1e-6)
+    assert np.allclose(sd.grad.cpu().numpy(), want_g, rtol=1e-4, atol=1e-7)
