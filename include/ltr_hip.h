@@ -254,6 +254,14 @@ int ltr_pbm_clicks(const int64_t *rankings, const int64_t *ys, const int64_t *n,
 int ltr_collate_pad_f32(const float *xs, const int64_t *ys, const int64_t *offsets,
                         const int64_t *qidx, const int64_t *sel, int Q, int B, int L, int F,
                         float *out_x, int64_t *out_y, int64_t *out_n, void *stream);
+/* The sparse branch of the same collate (svmrank.py:162-176,197-202).  The split is CSR in device memory:
+ * indptr (N + 1) int64 over ALL documents of the split, indices (nnz) int32 feature ids, values (nnz) fp32;
+ * ys / offsets / qidx / sel / outputs as above.  The batch comes out DENSE and padded -- what the loss
+ * kernels consume and what the reference's sparse batch is after .to_dense(); duplicate (row, column)
+ * entries add up (torch coalesce()).  F * 16 bytes of LDS must fit a workgroup (F <= 10236). */
+int ltr_collate_pad_csr_f32(const int64_t *indptr, const int32_t *indices, const float *values,
+                            const int64_t *ys, const int64_t *offsets, const int64_t *qidx, const int64_t *sel,
+                            int Q, int B, int L, int F, float *out_x, int64_t *out_y, int64_t *out_n, void *stream);
 
 /*
  * Linear scorer fused with the loss: the caller of the path in every reference workflow,

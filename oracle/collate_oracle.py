@@ -34,3 +34,19 @@ def collate_dense(xs, ys, offsets, indices, sampler_calls, max_list_size=None):
             out_y[b, :hi - lo] = ys[lo:hi]
         out_n[b] = min(hi - lo, list_size)
     return out_x, out_y, out_n
+
+
+def collate_csr(indptr, indices, values, num_features, ys, offsets, batch, sampler_calls, max_list_size=None):
+    """The sparse branch (svmrank.py:162-176,197-202) restated on a CSR split: the dense form of the batch.
+    For samples that fit the list this is exactly the reference's sparse batch `.to_dense()`.  For truncated
+    samples the reference's sparse branch indexes its COO columns with `sum(mask)` -- an integer tensor
+    where a boolean mask was meant -- and returns arbitrary entries (its own tests check the SHAPE only,
+    tests/datasets/svmrank/test_svmrank.py:196-268); the restatement gathers the sampled rows like the
+    dense branch does, which is what the code evidently intends."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    N = len(indptr) - 1
+    dense = np.zeros((N, num_features), dtype=np.float32)
+    for r in range(N):
+        for e in range(indptr[r], indptr[r + 1]):
+            dense[r, indices[e]] += np.float32(values[e])
+    return collate_dense(dense, ys, offsets, batch, sampler_calls, max_list_size)

@@ -56,6 +56,7 @@ SIGNATURES = {
     "ltr_plackettluce_keys_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "ltr_pbm_clicks": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
     "ltr_collate_pad_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ltr_collate_pad_csr_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ltr_linear_workspace_bytes": (_sz, [_i, _i, _i]),
     "ltr_linear_fused_plan": (_i, [_i, _i, _i, _i]),
     "ltr_overlap_create": (_i, [_vp, _vp, _i, _vp]),

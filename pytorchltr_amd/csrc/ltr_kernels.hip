@@ -775,6 +775,50 @@ __global__ void collate_pad_kernel(const V *__restrict__ xs, const int64_t *__re
     }
 }
 
+// The sparse branch of the same collate (svmrank.py:162-176,197-202: sparse SVMRankItems; the reference
+// returns a torch sparse COO batch whose dense form is the padded (B, L, F) batch).  Here the split lives
+// in HBM as CSR -- row pointers over all documents, column indices, values -- and is gathered straight
+// into the DENSE padded batch the loss kernels consume: one wave per output row builds the row in LDS
+// (zero fill, scatter its non-zeros) and stores it coalesced; duplicate column entries of a row add up,
+// as torch's coalesce() does.
+__global__ void __launch_bounds__(256)
+collate_pad_csr_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                       const float *__restrict__ values, const int64_t *__restrict__ ys,
+                       const int64_t *__restrict__ offsets, const int64_t *__restrict__ qidx,
+                       const int64_t *__restrict__ sel, int Q, int L, int F, float *__restrict__ out_x,
+                       int64_t *__restrict__ out_y, int64_t *__restrict__ out_n)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int64_t q = qidx[b];
+    if (q < 0) q = 0;
+    if (q >= Q) q = Q - 1;
+    const int64_t off = offsets[q];
+    const int64_t cnt = offsets[q + 1] - off;
+    const int nout = (int)(cnt < (int64_t)L ? cnt : (int64_t)L);
+    const int64_t *srow = sel ? sel + (size_t)b * L : nullptr;
+    float *rowbuf = reinterpret_cast<float *>(smem) + (size_t)wave * F;
+    for (int l = blockIdx.y * nw + wave; l < L; l += gridDim.y * nw) {
+        for (int f = lane; f < F; f += 64) rowbuf[f] = 0.f;
+        if (l < nout) {
+            const int64_t src = off + (srow ? srow[l] : (int64_t)l);
+            const int64_t p0 = indptr[src], p1 = indptr[src + 1];
+            for (int64_t e = p0 + lane; e < p1; e += 64) {
+                const int col = indices[e];
+                if (col >= 0 && col < F) atomicAdd(&rowbuf[col], values[e]);      // (LDS; duplicates add up)
+            }
+        }
+        float *ox = out_x + ((size_t)b * L + l) * F;
+        for (int f = lane; f < F; f += 64) ox[f] = rowbuf[f];
+    }
+    if (blockIdx.y == 0) {
+        for (int l = threadIdx.x; l < L; l += blockDim.x)
+            out_y[(size_t)b * L + l] = (l < nout) ? ys[off + (srow ? srow[l] : (int64_t)l)] : 0;
+        if (threadIdx.x == 0) out_n[b] = nout;
+    }
+}
+
 struct LaunchShape { int owners, dpt, msplit; };
 
 // dpt == 0: symmetric pair pass -- LDS rows padded to 64-wide tiles, one gradient slice per wave
@@ -1340,6 +1384,24 @@ int ltr_collate_pad_f32(const float *xs, const int64_t *ys, const int64_t *offse
     else
         hipLaunchKernelGGL((collate_pad_kernel<float>), grid, block, 0, (hipStream_t)stream, xs, ys,
                            offsets, qidx, sel, Q, L, C, out_x, out_y, out_n);
+    return (int)hipGetLastError();
+}
+
+int ltr_collate_pad_csr_f32(const int64_t *indptr, const int32_t *indices, const float *values,
+                            const int64_t *ys, const int64_t *offsets, const int64_t *qidx, const int64_t *sel,
+                            int Q, int B, int L, int F, float *out_x, int64_t *out_y, int64_t *out_n, void *stream)
+{
+    LTR_CLEAR_STALE_ERROR();
+    if (B < 0 || L <= 0 || F <= 0 || Q <= 0) return LTR_ERR_SHAPE;
+    if ((size_t)F * 4 * 4 > kLdsBudget) return LTR_ERR_SHAPE;          // four row buffers per workgroup
+    if (B == 0) return LTR_OK;
+    if (!indptr || !indices || !values || !ys || !offsets || !qidx || !out_x || !out_y || !out_n) return LTR_ERR_NULL;
+    unsigned gy = (unsigned)((L + 3) / 4);
+    if (gy > 64) gy = 64;
+    const size_t lds = (size_t)F * 4 * 4;
+    LTR_ENSURE_LDS(collate_pad_csr_kernel, lds);
+    hipLaunchKernelGGL(collate_pad_csr_kernel, dim3((unsigned)B, gy), dim3(256), lds, (hipStream_t)stream,
+                       indptr, indices, values, ys, offsets, qidx, sel, Q, L, F, out_x, out_y, out_n);
     return (int)hipGetLastError();
 }
 

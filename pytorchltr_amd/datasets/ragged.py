@@ -32,17 +32,39 @@ class RaggedQueries(_torch.utils.data.Dataset):
     """A split of a learning-to-rank dataset resident on the device.
 
     Args:
-        features: (N, F) float32, the documents of all queries, query after query.
+        features: (N, F) float32, the documents of all queries, query after query (None with `csr`).
         relevance: (N,) int64 labels.
         offsets: (Q + 1,) int64, documents of query q are rows offsets[q]:offsets[q+1].
         qids: optional (Q,) int64 query ids (default 0..Q-1).
         device: ROCm device the split lives on.
+        csr: optional (indptr (N + 1), indices (nnz), values (nnz)): the split stored sparsely -- the reference's
+            ``sparse=True`` datasets (svmrank.py:62-76,162-176); batches still come out dense and padded.
+        num_features: F of a csr split (default: largest feature id + 1).
     """
 
-    def __init__(self, features, relevance, offsets, qids=None, device="cuda"):
-        features = _torch.as_tensor(features, dtype=_torch.float32)
+    def __init__(self, features, relevance, offsets, qids=None, device="cuda", csr=None, num_features=None):
         relevance = _torch.as_tensor(relevance, dtype=_torch.int64)
         offsets = _torch.as_tensor(offsets, dtype=_torch.int64).cpu()
+        self.csr = None
+        if csr is not None:
+            # the sparse branch (svmrank.py:162-176): the split as CSR, collated into DENSE padded batches
+            indptr, indices, values = csr
+            indptr = _torch.as_tensor(indptr, dtype=_torch.int64)
+            indices = _torch.as_tensor(indices, dtype=_torch.int32)
+            values = _torch.as_tensor(values, dtype=_torch.float32)
+            if indptr.dim() != 1 or indptr.numel() != relevance.shape[0] + 1 or int(indptr[0]) != 0 or \
+                    int(indptr[-1]) != indices.numel() or indices.numel() != values.numel() or \
+                    bool((indptr[1:] < indptr[:-1]).any()):
+                raise ValueError("csr must be (indptr (N + 1), indices (nnz), values (nnz)) over the N documents")
+            if num_features is None:
+                num_features = int(indices.max()) + 1 if indices.numel() else 1
+            if indices.numel() and (int(indices.min()) < 0 or int(indices.max()) >= num_features):
+                raise ValueError("feature ids must lie in [0, num_features)")
+            self.num_features = int(num_features)
+            features = _torch.empty(relevance.shape[0], 0)
+        else:
+            features = _torch.as_tensor(features, dtype=_torch.float32)
+            self.num_features = None if features.dim() != 2 else int(features.shape[1])
         if features.dim() != 2 or relevance.dim() != 1 or features.shape[0] != relevance.shape[0]:
             raise ValueError("features must be (N, F) and relevance (N,)")
         if offsets.dim() != 1 or offsets.numel() < 1 or int(offsets[0]) != 0 or \
@@ -58,7 +80,21 @@ class RaggedQueries(_torch.utils.data.Dataset):
         self.features = features.to(dev).contiguous()
         self.relevance = relevance.to(dev).contiguous()
         self.offsets = offsets.to(dev)
-        _C.require_device(self.features, "features")
+        if csr is not None:
+            self.csr = (indptr.to(dev).contiguous(), indices.to(dev).contiguous(), values.to(dev).contiguous())
+        _C.require_device(self.relevance, "relevance")
+
+    @classmethod
+    def from_dense_as_csr(cls, features, relevance, offsets, qids=None, device="cuda"):
+        """A dense split stored sparsely (its non-zeros as CSR) -- e.g. the one-hot / bag-of-words feature
+        sets the reference loads with ``sparse=True``."""
+        x = _torch.as_tensor(features, dtype=_torch.float32)
+        nz = x != 0
+        counts = nz.sum(dim=1)
+        indptr = _torch.cat([_torch.zeros(1, dtype=_torch.int64), _torch.cumsum(counts, 0)])
+        rows, cols = nz.nonzero(as_tuple=True)
+        return cls(None, relevance, offsets, qids=qids, device=device,
+                   csr=(indptr, cols.to(_torch.int32), x[rows, cols]), num_features=x.shape[1])
 
     def __len__(self):
         return self._q
@@ -109,14 +145,20 @@ class RaggedQueries(_torch.utils.data.Dataset):
             idx = idx[order]
         B = idx.numel()
         list_size, select = self.plan(idx.tolist(), list_sampler)
-        dev = self.features.device
-        F = self.features.shape[1]
+        dev = self.relevance.device
+        F = self.num_features
         out_x = _torch.empty(B, list_size, F, dtype=_torch.float32, device=dev)
         out_y = _torch.empty(B, list_size, dtype=_torch.int64, device=dev)
         out_n = _torch.empty(B, dtype=_torch.int64, device=dev)
         qidx = idx.to(dev)
         sel = None if select is None else select.to(dev).contiguous()
-        if B > 0 and list_size > 0:
+        if B > 0 and list_size > 0 and self.csr is not None:
+            with _C.device_ctx(out_x):
+                _C.check(_C.lib().ltr_collate_pad_csr_f32(
+                    _C.ptr(self.csr[0]), _C.ptr(self.csr[1]), _C.ptr(self.csr[2]), _C.ptr(self.relevance),
+                    _C.ptr(self.offsets), _C.ptr(qidx), _C.ptr(sel), self._q, B, list_size, F, _C.ptr(out_x),
+                    _C.ptr(out_y), _C.ptr(out_n), _C.stream_of(out_x)))
+        elif B > 0 and list_size > 0:
             with _C.device_ctx(out_x):
                 _C.check(_C.lib().ltr_collate_pad_f32(
                     _C.ptr(self.features), _C.ptr(self.relevance), _C.ptr(self.offsets),

@@ -209,3 +209,71 @@ def test_query_indices_are_validated():
             ds[bad]
         with pytest.raises(IndexError):
             ds.collate([0, bad])
+
+
+# ---- the sparse branch (svmrank.py:162-176,197-202): CSR split -> dense padded batch ----
+VS = np.load(os.path.join(HERE, "golden", "collate_sparse_vectors.npz"))
+with open(os.path.join(HERE, "golden", "collate_sparse_vectors.json")) as fh:
+    SPARSE_CASES = json.load(fh)["cases"]
+
+
+def _sparse_sampler(case):
+    kw = {"generator": torch.Generator().manual_seed(case["seed"])} if case["seed"] is not None else {}
+    return (ListSampler if case["sampler"] == "list" else UniformSampler)(case["max_list_size"], **kw)
+
+
+@pytest.mark.parametrize("case", SPARSE_CASES, ids=[c["name"] for c in SPARSE_CASES])
+def test_sparse_collate_oracle_matches_reference(case):
+    """The numpy restatement on the CSR split == the dense form of the reference's sparse batch (for
+    truncated samples: == the reference's dense-branch batch, see oracle/collate_oracle.py:collate_csr)."""
+    from oracle.collate_oracle import collate_csr
+    sp, name = case["split"], case["name"]
+    calls = [VS[name + "/call%d" % k] for k in range(case["n_calls"])]
+    ox, oy, on = collate_csr(VS[sp + "/indptr"], VS[sp + "/indices"], VS[sp + "/values"], case["features"],
+                             VS[sp + "/ys"], VS[sp + "/offsets"], VS[name + "/indices"].tolist(), calls,
+                             case["max_list_size"])
+    assert tuple(ox.shape) == tuple(VS[name + "/shape"])
+    assert np.array_equal(ox, VS[name + "/features"])
+    assert np.array_equal(oy, VS[name + "/relevance"]) and np.array_equal(on, VS[name + "/n"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", SPARSE_CASES, ids=[c["name"] for c in SPARSE_CASES])
+def test_device_sparse_collate_matches_reference(case):
+    """ltr_collate_pad_csr_f32 through RaggedQueries(csr=...) == the reference's sparse batch, densified,
+    bit for bit; relevance, n and the list size as the reference computes them."""
+    from pytorchltr_amd.datasets import RaggedQueries
+    sp, name = case["split"], case["name"]
+    ragged = RaggedQueries(None, VS[sp + "/ys"], VS[sp + "/offsets"], device="cuda:0",
+                           csr=(VS[sp + "/indptr"], VS[sp + "/indices"], VS[sp + "/values"]),
+                           num_features=case["features"])
+    batch = ragged.collate(VS[name + "/indices"].tolist(), _sparse_sampler(case))
+    assert tuple(batch.features.shape) == tuple(VS[name + "/shape"])
+    assert np.array_equal(batch.features.cpu().numpy(), VS[name + "/features"])           # bit-exact
+    assert np.array_equal(batch.relevance.cpu().numpy(), VS[name + "/relevance"])
+    assert np.array_equal(batch.n.cpu().numpy(), VS[name + "/n"])
+
+
+@pytest.mark.gpu
+def test_sparse_and_dense_storage_collate_to_the_same_batch():
+    """A dense split stored as CSR (from_dense_as_csr) collates to the same batch as the dense storage,
+    samplers included; duplicate entries of a (row, column) add up like torch's coalesce()."""
+    from pytorchltr_amd.datasets import RaggedQueries, UniformSampler as US
+    g = torch.Generator().manual_seed(8)
+    counts = torch.randint(1, 50, (30,), generator=g)
+    offsets = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)])
+    N = int(offsets[-1])
+    xs = torch.randn(N, 136, generator=g) * (torch.rand(N, 136, generator=g) < 0.2)
+    ys = torch.randint(0, 5, (N,), generator=g)
+    dense = RaggedQueries(xs, ys, offsets, device="cuda:0")
+    sparse = RaggedQueries.from_dense_as_csr(xs, ys, offsets, device="cuda:0")
+    idx = list(range(0, 30, 2))
+    for limit in (None, 20):
+        a = dense.collate(idx, US(limit, generator=torch.Generator().manual_seed(1)))
+        b = sparse.collate(idx, US(limit, generator=torch.Generator().manual_seed(1)))
+        assert torch.equal(a.features, b.features) and torch.equal(a.relevance, b.relevance) and torch.equal(a.n, b.n)
+    dup = RaggedQueries(None, torch.tensor([1, 0]), torch.tensor([0, 2]), device="cuda:0",
+                        csr=(torch.tensor([0, 3, 3]), torch.tensor([2, 0, 2]), torch.tensor([1.5, 4.0, 2.0])),
+                        num_features=4)
+    out = dup.collate([0]).features.cpu()
+    assert out.tolist() == [[[4.0, 0.0, 3.5, 0.0], [0.0, 0.0, 0.0, 0.0]]]
