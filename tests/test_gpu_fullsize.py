@@ -207,3 +207,48 @@ def test_cluster_wait_timeout_is_an_error_not_a_silent_nan(shape):
     torch.cuda.synchronize()
     for a, g in zip(again, good):
         assert torch.equal(a, g)
+
+
+@pytest.mark.parametrize("shape", [("hinge", 100, 2000, 64), ("dcg_hinge", 60, 2048, 32), ("hinge", 300, 1000, 512),
+                                   ("dcg_hinge", 280, 700, 700)])
+def test_parts_kernel_ranked_hinge_all_rows(shape):
+    """The hinge kinds on long lists take the counting formulation (buckets by score, per-grade count and sum
+    tables, exact visits of the edge buckets) instead of the O(n^2) pair pass: every row against the oracle --
+    the gradients are integers and must come out exactly, the loss to the long-list tolerance -- run twice,
+    bit-identical.  Lists straddle the per-query threshold (rows * n), so both formulations are in the batch."""
+    from pytorchltr_amd import _C
+    kind, B, L, F = shape
+    _run(kind, B, L, F, 6, _C.PLAN_PARTS)
+
+
+@pytest.mark.parametrize("variant", ["float_labels", "grade_7", "tied_scores", "tiny_spread", "constant"])
+def test_parts_kernel_ranked_hinge_falls_back(variant):
+    """Queries the counting formulation does not take (labels that are not the integers 0..4, scores without
+    spread) fall back to the pair pass, per query, and queries full of tied scores stay exact."""
+    from pytorchltr_amd import _C
+    from pytorchltr_amd.fused import linear_loss_step
+    dev = _dev()
+    B, L, F = 40, 2000, 64
+    assert _C.lib().ltr_linear_fused_plan(_C.HINGE, B, L, F) == _C.PLAN_PARTS
+    s, y, n, X, W, b = synth(B, L, 9, F=F)
+    n = torch.clamp(n, min=1500)
+    yy = y.clone()
+    if variant == "float_labels":
+        yy = y.float() + 0.5 * (torch.arange(B)[:, None] % 2)          # every other query: half-integer labels
+    elif variant == "grade_7":
+        yy[::3] = yy[::3] + 3                                            # grades up to 7 in a third of the queries
+    elif variant == "tied_scores":
+        X = torch.round(X * 2) / 2                                       # few distinct feature values ...
+        W = torch.round(W * 8) / 8                                       # ... and weights: many exactly equal scores
+    elif variant == "tiny_spread":
+        X = X * 1e-7
+    elif variant == "constant":
+        X = torch.zeros_like(X)
+    kind = "hinge"
+    loss, dW, db = linear_loss_step(X.to(dev), W.to(dev), b.to(dev), yy.to(dev), n.to(dev), loss=kind)
+    want_l, _, want_dW, want_db = O.linear_pairwise(kind, X.numpy(), W.numpy(), float(b[0]), yy.numpy(), n.numpy(),
+                                                    np.full(B, 1.0 / B))
+    assert np.allclose(loss.cpu().numpy(), want_l, rtol=5e-4, atol=1e-5), variant
+    tol = 2e-4 * max(1.0, float(np.max(np.abs(want_dW))))
+    assert np.max(np.abs(dW.cpu().numpy() - want_dW)) < tol, variant
+    _C.device_status()
