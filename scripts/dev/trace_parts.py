@@ -63,3 +63,9 @@ f = t[t[:, 15] != 0].double()
 print("prologue phases (us, mean): n+ballots %.2f | prefix+table+order %.2f | ctrl %.2f | to first stamp %.2f" % (
     float(((f[:, 10] - f[:, 15]) / 100).mean()), float(((f[:, 11] - f[:, 10]) / 100).mean()),
     float(((f[:, 12] - f[:, 11]) / 100).mean()), float(((f[:, 0] - f[:, 12]) / 100).mean())))
+
+rk = t[(t[:, 14] > t[:, 4]) & (t[:, 14] < t[:, 5]) & (t[:, 10] > t[:, 4])].double()
+if rk.shape[0]:
+    names = ["S1 qualify", "S2-3 hist+scan", "S4 scatter", "S5 bucket sort+agg", "S6 scans", "S7 rows+sum"]
+    seg = [rk[:, 10] - rk[:, 4], rk[:, 11] - rk[:, 10], rk[:, 12] - rk[:, 11], rk[:, 13] - rk[:, 12], rk[:, 14] - rk[:, 13], rk[:, 5] - rk[:, 14]]
+    print("ranked parts %d: " % rk.shape[0] + " | ".join("%s %.2f" % (n_, float(v.mean()) / 100) for n_, v in zip(names, seg)))
