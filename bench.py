@@ -261,13 +261,27 @@ class FusedStep:
         self.reduce(accumulate, flat)
 
 
+PMC_STALE = set()     # workloads whose committed counters belong to older kernel sources
+
+
 def pmc_record(workload):
     """PMC-derived per-launch figures of the workload's kernels (profiles/pmc_<workload>.json,
     written by scripts/pmc_to_json.py from separate rocprofv3 --pmc passes of this command)."""
     path = os.path.join(ROOT, "profiles", "pmc_%s.json" % workload)
     if os.path.exists(path):
         with open(path) as fh:
-            return json.load(fh)
+            doc = json.load(fh)
+        # stale-counter guard (VERDICT r2 item 8): counters taken from other kernel sources than the tree's
+        # are not printed -- `traffic` / `valu_issue_frac` then read null until the passes are re-run
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        try:
+            from pmc_to_json import csrc_sha256
+            if doc.get("_csrc_sha256") != csrc_sha256(ROOT):
+                PMC_STALE.add(workload)
+                return {}
+        except Exception:  # pragma: no cover
+            return {}
+        return doc
     return {}
 
 
@@ -729,6 +743,9 @@ def main():
     out = None
     if rank == 0:
         extra = {"timed_regions_s": regions, "steps_per_region": steps_timed}
+        _ = pmc_record(args.workload)
+        extra["pmc_counters"] = ("profiles/pmc_<workload>.json (separate rocprofv3 --pmc passes); refused when the kernel "
+                                 "sources changed since: stale for %s" % (sorted(PMC_STALE) or "none"))
         if accum8 is not None:
             extra["gradient_accumulation_8"] = accum8
         # ---- roofline of the dominant kernel: fused scorer+loss, cold, timed live with HIP events ----

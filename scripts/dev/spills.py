@@ -13,5 +13,5 @@ for ln in out.splitlines():
         if m and rows: rows[-1][key] = int(m.group(1))
 for r in rows:
     if "linear_parts_kernel" in r["name"]:
-        t = re.search(r"ILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", r["name"]).groups()
-        print("kind %s ni %s cv %s wpc %s: vgpr %s spill %s" % (*t, r.get("VGPRs"), r.get("VGPRs Spill")))
+        t = re.search(r"ILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)E", r["name"]).groups()
+        print("kind %s ni %s cv %s wpc %s rk %s: vgpr %s spill %s" % (*t, r.get("VGPRs"), r.get("VGPRs Spill")))

@@ -7,10 +7,26 @@
 Per kernel of the fused step: HBM bytes per launch with the gfx950 correction of
 MI355X_MICROARCH.md (FETCH_SIZE reports 1/2 of the bytes of wide coalesced streaming reads ->
 doubled; WRITE_SIZE as reported; both in KB), VALU / SALU wave-instructions per launch."""
+import hashlib
 import json
+import os
 import sys
 
+
+def csrc_sha256(root=None):
+    """Fingerprint of the kernel sources the counters were taken from (bench.py refuses counters whose
+    fingerprint differs from the tree's: a rebuilt kernel must not carry stale traffic figures)."""
+    root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "pytorchltr_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".inc")):
+            with open(os.path.join(d, name), "rb") as fh:
+                h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
 KEYS = {"linear_regtile_kernel": "linear_regtile", "linear_cluster_kernel": "linear_cluster_kernel",
+        "linear_parts_kernel": "linear_parts_kernel", "stream_probe_kernel": "stream_probe_kernel",
         "linear_pairwise_kernel": "linear_pairwise_kernel", "pairwise_loss_kernel": "pairwise_loss_kernel",
         "linear_reduce_kernel": "linear_reduce_kernel", "metric_kernel": "metric_kernel"}
 
@@ -27,7 +43,8 @@ def main(workload, fetch, write, sq):
     docs = [json.load(open(p)) for p in (fetch, write, sq)]
     out = {"_source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_* (separate passes) -- "
                       "python bench.py --workload %s --no-extra --no-cpu-baseline; FETCH_SIZE doubled "
-                      "(gfx950: wide coalesced reads are tallied at half their bytes, MI355X_MICROARCH.md)" % workload}
+                      "(gfx950: wide coalesced reads are tallied at half their bytes, MI355X_MICROARCH.md)" % workload,
+           "_csrc_sha256": csrc_sha256()}
     for key, needle in KEYS.items():
         f, w, s = (pick(d, needle) for d in docs)
         if not f and not s:
