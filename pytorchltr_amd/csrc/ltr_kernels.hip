@@ -111,6 +111,7 @@ pairwise_loss_kernel(LossParams p)
 
     float gscale, gsum;
     float total;
+    constexpr bool kDefer = NW > 0 && NW <= 8;     // 1 / maxDCG applied once, after the pair pass
     if constexpr (kSym) {
         if (KIND == LTR_NDCG1 || KIND == LTR_NDCG2) {
             int owners = 64;
@@ -119,9 +120,9 @@ pairwise_loss_kernel(LossParams p)
             const int mlen = (nb + ms - 1) / ms;
             const int m0 = __builtin_amdgcn_readfirstlane(min(nb, (tid / owners) * mlen));
             const int m1 = __builtin_amdgcn_readfirstlane(min(nb, m0 + mlen));
-            prepare_ndcg<KIND, 1, NW>(q, nb, owners, tid % owners, m0, m1, ms > 1);
+            prepare_ndcg<KIND, 1, NW, kDefer>(q, nb, owners, tid % owners, m0, m1, ms > 1);
         }
-        total = pairwise_core_sym<KIND, NW>(q, nb, L4, p.sigma, gscale);
+        total = pairwise_core_sym<KIND, NW, kDefer>(q, nb, L4, p.sigma, gscale);
         gsum = 0.f;
     } else {
         total = pairwise_core<KIND, (DPT > 0 ? DPT : 1)>(q, nb, L4, msplit, p.sigma, gscale, gsum);
@@ -244,9 +245,7 @@ pairwise_loss_split_kernel(LossParams p, int nsplit, int part_major, float *ws, 
                 q.q4[k] = make_float4(sv.x, sv.y, v.x, v.y);
             }
         }
-        if (KIND == LTR_NDCG2)
-            for (int d = tid; d < nb; d += T)               // delta table, pairwise_lambda.py:206-211
-                q.delta[d] = fabsf(1.0f / log2f(2.0f + (float)d) - 1.0f / log2f(3.0f + (float)d));
+        if (KIND == LTR_NDCG2) fill_ndcg2_delta(q.delta, nb, L4, tid, T);   // pairwise_lambda.py:206-211
         __syncthreads();
     }
     float unused = 1.0f;
