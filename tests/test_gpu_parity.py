@@ -206,6 +206,37 @@ def test_long_lists_both_pair_passes(kind, shape):
     _check_grad(ds, want_g, "%s %s" % (kind, cfg), exact=(kind == "hinge"))
 
 
+@pytest.mark.parametrize("kind", ["logistic", "arp1", "arp2", "ndcg1", "ndcg2"])
+@pytest.mark.parametrize("L", [37, 128, 300])
+def test_real_valued_labels_and_far_apart_scores(kind, L):
+    """The log-sigmoid kinds on labels that are neither integers nor non-negative (LambdaNDCG2 reads the pair's
+    orientation off the signed gain difference: the gains order documents as the labels do, negative labels
+    included), with ties among the labels, and on scores so far apart that exp(-sigma d) is below 1e-5 for most
+    pairs (log2(1 + e) without a series branch): loss and gradients against the fp64 oracle."""
+    rng = np.random.default_rng(1234 + L)
+    B = 6
+    n = np.array([L, L - 1, max(1, L // 2), 2, 1, 0], dtype=np.int64)
+    # (the row-weight kinds raise a sigmoid to the power of the label / gain: with far-apart scores a negative
+    # exponent overflows in the reference's own formulation, fp64 included -- non-negative labels there)
+    lo = 0.0 if kind in ("arp1", "ndcg1") else -1.5
+    y = rng.uniform(lo, 3.0, size=(B, L)).astype(np.float32)
+    y[:, ::5] = y[:, 1::5][:, :y[:, ::5].shape[1]]            # tied labels
+    y[1] = np.round(y[1])                                       # one row of (partly negative) integers
+    s = rng.normal(size=(B, L)).astype(np.float32)
+    # (e = exp(-step k) for documents k places apart: every regime down to the smallest e; the largest
+    # difference stays below what exp() takes in fp64, where the oracle follows the reference's formulation)
+    # (LambdaARP1 raises the sigmoid to the label: a third of that range)
+    span = 200.0 if kind == "arp1" else 600.0
+    s[2] = (np.arange(L, dtype=np.float32) * np.float32(min(12.0, span / L)))[rng.permutation(L)]
+    s[3] = s[3] * 30.0
+    if kind == "arp1":
+        s[3] = s[3] / 3.0
+    loss, ds = _run_direct(kind, s, y, n)
+    want_l, want_g = O.pairwise_loss(kind, s, y, n)
+    _check_loss(loss, want_l, L, "%s L=%d" % (kind, L))
+    _check_grad(ds, want_g, "%s L=%d" % (kind, L))
+
+
 def test_ties_follow_the_documented_rule():
     """Ties: score descending, then index ascending -- identical to the oracle."""
     from pytorchltr_amd.utils import rank_by_score
