@@ -122,7 +122,9 @@ pairwise_loss_kernel(LossParams p)
             const int m1 = __builtin_amdgcn_readfirstlane(min(nb, m0 + mlen));
             prepare_ndcg<KIND, 1, NW, kDefer>(q, nb, owners, tid % owners, m0, m1, ms > 1);
         }
-        total = pairwise_core_sym<KIND, NW, kDefer>(q, nb, L4, p.sigma, gscale);
+        const bool intlab = (KIND == LTR_HINGE || KIND == LTR_DCG_HINGE) && p.rel_dtype != LTR_LABEL_F32;
+        total = intlab ? pairwise_core_sym<KIND, NW, kDefer, true>(q, nb, L4, p.sigma, gscale)
+                       : pairwise_core_sym<KIND, NW, kDefer, false>(q, nb, L4, p.sigma, gscale);
         gsum = 0.f;
     } else {
         total = pairwise_core<KIND, (DPT > 0 ? DPT : 1)>(q, nb, L4, msplit, p.sigma, gscale, gsum);
