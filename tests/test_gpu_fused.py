@@ -47,6 +47,28 @@ def _check(kind, B, L, F, seed, sigma=1.0, full=False, grad_out=None):
     assert abs(float(db2.cpu()[0]) - want_db) < tol, kind
 
 
+def _random_shapes(count, seed):
+    import random
+    rnd = random.Random(seed)
+    out = []
+    for _ in range(count):
+        B = rnd.choice([1, 2, 3, 7, 33, 64, 130, 257, 600])
+        L = rnd.choice([1, 2, 5, 31, 64, 65, 100, 128, 129, 200, 257, 300, 511, 777, 1000, 1030])
+        F = rnd.choice([4, 8, 12, 36, 64, 136, 220, 260, 700])
+        if B * L * F > 20_000_000:
+            B = max(1, 20_000_000 // (L * F))
+        out.append((B, L, F, rnd.choice(list(KINDS))))
+    return out
+
+
+@pytest.mark.parametrize("shape", _random_shapes(48, 20260929), ids=lambda s: "%dx%dx%d-%s" % s)
+def test_fused_step_random_shapes(shape):
+    """Seeded random (B, L, F, kind): whatever plan the dispatcher picks (register tile, cluster, parts,
+    general kernel), every query's loss, the scores, dW and db against the fp64 oracle."""
+    B, L, F, kind = shape
+    _check(kind, B, L, F, seed=B + L + F)
+
+
 @pytest.mark.parametrize("kind", KINDS)
 def test_fused_step_small_shapes(kind):
     _check(kind, 8, 16, 5, 1234)                 # scalar path (F % 4 != 0), Example3-like F
