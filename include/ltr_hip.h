@@ -81,8 +81,25 @@ int ltr_max_list_len_f64(void);
  * fail at run time.
  */
 int ltr_device_status(int clear);
-/* Tests only: != 0 makes every in-launch wait of the cluster kernel give up at once. */
+/* Tests only: != 0 makes every in-launch wait of the multi-workgroup kernels give up at once. */
 void ltr_debug_force_timeout(int on);
+/*
+ * Exchange areas.  The fused-scorer kernels that spread a query over several workgroups (the parts kernel
+ * behind ltr_linear_partials_f32 / ltr_linear_pairwise_f32 / ltr_linear_step_f32 for long lists and wide rows)
+ * hand scores and gradient slices to each other through device memory as tagged 8-byte granules, next to a few
+ * self-resetting counters.  That memory is NOT part of the caller's workspace: the library owns it -- one area
+ * per (device, stream) for eager launches, a private one for every call made under stream capture (allocated
+ * with the thread's capture mode relaxed; the allocation is not part of the captured work) --, zeroes it when
+ * it is allocated and never hands it to anybody else, so the kernels never read uninitialised memory.  Areas
+ * grow on demand and stay allocated; ltr_exchange_release() frees them all and may only be called when no
+ * launch that used one is in flight and no captured graph containing one will be replayed again.  After a
+ * launch that gave up (LTR_ERR_TIMEOUT) the areas are zeroed again before their next use, once the status has
+ * been cleared with ltr_device_status(1).  The reference has no counterpart (one process, no device code).
+ */
+int ltr_exchange_release(void);
+/* Tests only: the granule tag the NEXT launch on `stream`'s exchange area uses (tags run 1 .. 2^32 - 1 and
+ * start over; the launch that uses the last one zeroes the granule buffers on its way out). */
+int ltr_debug_set_exchange_tag(void *stream, unsigned tag);
 /* Measurement aid (bench.py `roofline.launch_ceiling`): the launch geometry of the register-tile kernel --
  * one 512-thread workgroup per query, 16-byte buffer loads over the query's n[b] * F real floats, all in
  * flight at once -- with no computation behind the loads: every wave stores one dword to out
@@ -272,7 +289,9 @@ int ltr_collate_pad_csr_f32(const int64_t *indptr, const int32_t *indices, const
  * grad_out (B) may be NULL, meaning 1/B for every query (`.mean().backward()`).
  * Rows l >= n[b] are never read (their gradient is 0) unless scores_out is requested; when
  * the (L x F) tile fits one workgroup's registers the features cross HBM exactly once.
- * `workspace` needs ltr_linear_workspace_bytes(B,L,F) bytes (per-query partials).
+ * `workspace` needs ltr_linear_workspace_bytes(B,L,F) bytes (per-query partials); it may be uninitialised
+ * memory: everything in it is written before it is read (the kernels' cross-workgroup state lives in the
+ * library's exchange areas, see ltr_exchange_release).
  */
 size_t ltr_linear_workspace_bytes(int B, int L, int F);
 /* Which kernel ltr_linear_partials_f32 / ltr_linear_pairwise_f32 take for this shape when no score

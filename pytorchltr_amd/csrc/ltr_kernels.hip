@@ -1023,7 +1023,11 @@ int ltr_device_status(int clear)
     if (!sp.host) return LTR_OK;
     volatile int *w = reinterpret_cast<volatile int *>(sp.host);
     const int v = *w;
-    if (clear) *w = 0;
+    if (clear) {
+        *w = 0;
+        // the launch that gave up left counters of its exchange area behind: zero the areas before they are used again
+        if (v == LTR_ERR_TIMEOUT) ltr_internal_exchange_mark_dirty();
+    }
     return v;
 }
 
