@@ -4,7 +4,7 @@ device-only with -DLTR_DEV_SUBSET (hinge + logistic, symmetric split pass only) 
 import re, subprocess, sys
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-pthread", "-Wno-unused-function",
        "-Wno-bitwise-instead-of-logical", "-I", "include", "-I", "pytorchltr_amd/csrc", "--cuda-device-only", "-c",
-       "pytorchltr_amd/csrc/ltr_linear.hip", "-o", "/tmp/x%d.o" % __import__("os").getpid(), "-Rpass-analysis=kernel-resource-usage", "-DLTR_DEV_SUBSET"] + sys.argv[1:]
+       "pytorchltr_amd/csrc/ltr_linear.hip", "-o", "/tmp/x%d.o" % __import__("os").getpid(), "-Rpass-analysis=kernel-resource-usage"] + ([] if "--full" in sys.argv else ["-DLTR_DEV_SUBSET"]) + [a for a in sys.argv[1:] if a != "--full"]
 out = subprocess.run(cmd, stderr=subprocess.PIPE, stdout=subprocess.PIPE).stderr.decode()
 name = None
 rows = []

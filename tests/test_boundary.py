@@ -179,11 +179,11 @@ def test_fused_plan_for_the_baseline_shapes():
     lib = _C.lib()
     assert lib.ltr_linear_fused_plan(_C.HINGE, 1024, 128, 136) == _C.PLAN_REGISTER_TILE      # C2
     assert lib.ltr_linear_fused_plan(_C.NDCG2, 1024, 128, 136) == _C.PLAN_REGISTER_TILE      # C3
-    assert lib.ltr_linear_fused_plan(_C.DCG_HINGE, 256, 1000, 220) == _C.PLAN_PARTS          # C4 (symmetric split pass)
+    assert lib.ltr_linear_fused_plan(_C.DCG_HINGE, 256, 1000, 220) == _C.PLAN_CLUSTER        # C4
     assert lib.ltr_linear_fused_plan(_C.HINGE, 512, 512, 700) == _C.PLAN_PARTS               # C5
     assert lib.ltr_linear_fused_plan(_C.HINGE, 512, 512, 220) == _C.PLAN_GENERAL             # narrow rows
-    assert lib.ltr_linear_fused_plan(_C.HINGE, 64, 512, 700) == _C.PLAN_PARTS                # C5 shard of 8 GPUs
-    assert lib.ltr_linear_fused_plan(_C.DCG_HINGE, 32, 1000, 220) == _C.PLAN_PARTS           # C4 shard of 8 GPUs
+    assert lib.ltr_linear_fused_plan(_C.HINGE, 64, 512, 700) == _C.PLAN_CLUSTER              # C5 shard of 8 GPUs
+    assert lib.ltr_linear_fused_plan(_C.DCG_HINGE, 32, 1000, 220) == _C.PLAN_CLUSTER         # C4 shard of 8 GPUs
     assert lib.ltr_linear_fused_plan(_C.NDCG2, 512, 512, 700) == _C.PLAN_GENERAL             # rankings: not in parts
     assert lib.ltr_linear_fused_plan(_C.HINGE, 48, 2000, 64) == _C.PLAN_PARTS                # beyond the symmetric pass
     assert lib.ltr_linear_fused_plan(_C.NDCG2, 256, 1000, 220) == _C.PLAN_GENERAL            # rankings: small batches only

@@ -95,10 +95,10 @@ def test_parts_kernel_shapes_all_rows(shape):
 
 
 def test_parts_kernel_reuses_a_workspace_across_batches_and_shapes():
-    """The control block and the tagged score granules live in the caller's workspace and reset
-    themselves: the same buffer serves different batches, then a different shape (its control block
-    lands elsewhere and is brought up again), then the first shape again -- each step against the
-    oracle; a stale granule or counter from an earlier launch would show up here."""
+    """The control block and the tagged score granules live in the library's exchange area of the stream and
+    reset themselves: the same area serves different batches, then a different shape (other offsets inside
+    it), then the first shape again -- each step against the oracle; a stale granule or counter from an
+    earlier launch would show up here.  The caller's workspace holds only outputs and may start as garbage."""
     from pytorchltr_amd import _C
     dev = _dev()
     lib = _C.lib()
@@ -160,6 +160,71 @@ def test_parts_kernel_under_graph_replay():
     _C.device_status()
 
 
+def test_exchange_area_tag_wraps_around():
+    """The granules of the parts kernel carry a 32-bit tag that counts the launches on an exchange area (library-owned
+    device memory, include/ltr_hip.h: ltr_exchange_release); the launch that uses the last tag, 2^32 - 1, zeroes the
+    granule buffers on its way out and the next one starts over at 1.  ltr_debug_set_exchange_tag puts the area three
+    launches before the wrap: every step on either side of it must match the oracle (a stale granule that carried a
+    reused tag would be taken for a fresh score)."""
+    from pytorchltr_amd import _C
+    from pytorchltr_amd.fused import linear_loss_step
+    dev = _dev()
+    lib = _C.lib()
+    B, L, F = 70, 512, 700
+    assert lib.ltr_linear_fused_plan(_C.HINGE, B, L, F) == _C.PLAN_PARTS
+    s, y, n, X, W, b = synth(B, L, 77, F=F)
+    Xd, bd, yd, nd = X.to(dev), b.to(dev), y.to(dev), n.to(dev)
+    linear_loss_step(Xd, W.to(dev), bd, yd, nd, loss="hinge")          # (the area exists)
+    _C.check(lib.ltr_debug_set_exchange_tag(_C.stream_of(Xd), 0xFFFFFFFD))
+    for rep in range(6):
+        Wr = W * (1.0 + 0.25 * rep)
+        loss, dW, db = linear_loss_step(Xd, Wr.to(dev), bd, yd, nd, loss="hinge")
+        want_l, _, want_dW, _ = O.linear_pairwise("hinge", X.numpy(), Wr.numpy(), float(b[0]), y.numpy(), n.numpy(),
+                                                  np.full(B, 1.0 / B))
+        assert np.allclose(loss.cpu().numpy(), want_l, rtol=5e-4, atol=1e-5), rep
+        assert np.max(np.abs(dW.cpu().numpy() - want_dW)) < 2e-4 * max(1.0, float(np.max(np.abs(want_dW)))), rep
+    _C.device_status()
+
+
+def test_parts_kernel_captured_without_a_warm_up_launch():
+    """A call made under stream capture gets an exchange area of its own (allocated with the thread's capture mode
+    relaxed): a graph captured as the very first use of a shape replays correctly, next to eager launches of the same
+    shape on the same stream."""
+    from pytorchltr_amd import _C
+    dev = _dev()
+    lib = _C.lib()
+    B, L, F = 90, 520, 704
+    assert lib.ltr_linear_fused_plan(_C.HINGE, B, L, F) == _C.PLAN_PARTS
+    s, y, n, X, W, b = synth(B, L, 41, F=F)
+    Xd, Wd, bd, yd, nd = X.to(dev), W.to(dev), b.to(dev), y.to(dev), n.to(dev)
+    nbytes = lib.ltr_linear_workspace_bytes(B, L, F)
+    ws = torch.full((nbytes // 4 + 64,), float("nan"), device=dev)     # (the caller's workspace may hold anything)
+    loss = torch.empty(B, device=dev)
+    dW, db = torch.empty(F, device=dev), torch.empty(1, device=dev)
+
+    def step():
+        _C.check(lib.ltr_linear_pairwise_f32(_C.HINGE, 1.0, Xd.data_ptr(), Wd.data_ptr(), bd.data_ptr(),
+                                             yd.data_ptr(), _C.LABEL_I64, nd.data_ptr(), None, B, L, F,
+                                             loss.data_ptr(), None, dW.data_ptr(), db.data_ptr(),
+                                             ws.data_ptr(), nbytes, _C.stream_of(Xd)))
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    want_l, _, want_dW, _ = O.linear_pairwise("hinge", X.numpy(), W.numpy(), float(b[0]), y.numpy(), n.numpy(),
+                                              np.full(B, 1.0 / B))
+    for rep in range(3):
+        loss.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.allclose(loss.cpu().numpy(), want_l, rtol=5e-4, atol=1e-5), rep
+        assert np.max(np.abs(dW.cpu().numpy() - want_dW)) < 2e-4 * max(1.0, float(np.max(np.abs(want_dW)))), rep
+        step()                                                           # an eager launch in between
+        torch.cuda.synchronize()
+        assert np.allclose(loss.cpu().numpy(), want_l, rtol=5e-4, atol=1e-5), rep
+    _C.device_status()
+
+
 def test_c5_shard_of_8_gpus():
     from pytorchltr_amd import _C
     plan = _C.lib().ltr_linear_fused_plan(_C.HINGE, 64, 512, 700)
@@ -170,8 +235,8 @@ def test_c5_shard_of_8_gpus():
 def test_cluster_wait_timeout_is_an_error_not_a_silent_nan(shape):
     """ltr_debug_force_timeout makes every in-launch wait give up: the step's outputs are poisoned
     AND the sticky status word turns the next ltr_linear_* call into LTR_ERR_TIMEOUT.  Both kernels
-    whose workgroups wait for each other: the cluster kernel and the parts kernel (which also drops its
-    control block, so that the next launch brings it up again)."""
+    whose workgroups wait for each other: the cluster kernel and the parts kernel.  Clearing the status marks
+    the exchange areas dirty: they are zeroed before the next launch, which must be bit-identical to the first."""
     from pytorchltr_amd import _C
     from pytorchltr_amd.fused import linear_loss_step
     dev = _dev()
