@@ -203,6 +203,11 @@ def median(xs):
     return s[len(s) // 2]
 
 
+# learning rate of the timed synchronous-SGD step: small enough that the weights stay where the synthetic
+# batches were drawn for over the ~10^5 steps of a run (the step's cost does not depend on the values)
+SGD_LR = 1e-6
+
+
 def bucket_views(flat, F):
     """The one all-reduced bucket of a step, (F + 3) floats: [dW (F) | db | loss_sum | count]."""
     return flat[:F], flat[F:F + 1], flat[F + 1:F + 2], flat[F + 2:F + 3]
@@ -256,12 +261,22 @@ class FusedStep:
             self.F, self.lossv.data_ptr(), (self.flat if flat is None else flat).data_ptr(), 1 if accumulate else 0,
             self.part.data_ptr(), self.ws_bytes, None, 0, self._stream()))
 
+    def sgd_step(self, batch, lr=SGD_LR):
+        """The reference's whole training step in ONE C-ABI call (ltr_linear_sgd_step_f32): partials + reduce into
+        the bucket + W -= lr * dW, bias -= lr * db (at one rank the update rides in the reduction kernel)."""
+        self._C.check(self.lib.ltr_linear_sgd_step_f32(
+            self.kind_id, 1.0, batch["X"].data_ptr(), self.W.data_ptr(), self.bias.data_ptr(),
+            batch["rel"].data_ptr(), self._C.LABEL_I64, batch["n"].data_ptr(), self.go.data_ptr(), self.B, self.L,
+            self.F, float(lr), self.lossv.data_ptr(), self.flat.data_ptr(), self.part.data_ptr(), self.ws_bytes,
+            None, self._stream()))
+
     def step_two_calls(self, batch, accumulate=False, flat=None):
         self.kernel(batch)
         self.reduce(accumulate, flat)
 
 
 PMC_STALE = set()     # workloads whose committed counters belong to older kernel sources
+
 
 
 def pmc_record(workload):
@@ -647,7 +662,7 @@ def main():
     allreduce_impl = None
     if dist is None:
         def step(i):
-            fs.step(batches[i % nbuf])
+            fs.sgd_step(batches[i % nbuf])
     elif accum == 1:
         # one all-reduce per step, overlapped: step i writes bucket i % 2, its all-reduce is enqueued
         # asynchronously and runs under step i + 1; the compute stream waits for it only when the bucket
@@ -670,8 +685,12 @@ def main():
 
             def step(i):
                 b = batches[i % nbuf]
-                raw.step(i, fs.kind_id, 1.0, b["X"], fs.W, fs.bias, b["rel"], _C.LABEL_I64, b["n"], fs.go, B, L, F,
-                         fs.lossv, fs.part)
+                if mode == "instream":      # synchronous SGD: kernels, all-reduce, W -= lr * dW -- one C-ABI call
+                    raw.sgd_step(fs.kind_id, 1.0, b["X"], fs.W, fs.bias, b["rel"], _C.LABEL_I64, b["n"], fs.go, B, L, F,
+                                 SGD_LR, fs.lossv, fs.part)
+                else:
+                    raw.step(i, fs.kind_id, 1.0, b["X"], fs.W, fs.bias, b["rel"], _C.LABEL_I64, b["n"], fs.go, B, L, F,
+                             fs.lossv, fs.part)
         else:
             if raw is not None:
                 sys.stderr.write("[bench] raw RCCL communicator unavailable (%s): torch.distributed all_reduce\n" % raw.why)
@@ -683,7 +702,9 @@ def main():
                 flat = red.acquire(i)
                 fs.step(batches[i % nbuf], flat=flat)
                 red.launch(i)
-                red.result(i)
+                g = red.result(i)
+                fs.W.add_(g[:F], alpha=-SGD_LR)           # the optimiser step behind the collective
+                fs.bias.add_(g[F:F + 1], alpha=-SGD_LR)
     else:
         ar_view = fs.flat[:F + 2]                # (the count slot is not all-reduced again and again)
         fs.flat[F + 2] = float(B * n_gpus)
@@ -740,9 +761,21 @@ def main():
         accum8 = {"queries_per_s": n_gpus * B * n8 / median(r8), "ms_per_step": median(r8) / n8 * 1e3,
                   "allreduce_every": 8, "what": "gradient accumulation: 8 micro-batch steps per all-reduce"}
 
+    # the same step without the weight update (what rounds 1-3 reported as `value`)
+    noupd = None
+    if dist is None:
+        for i in range(2 * nbuf):
+            fs.step(batches[i % nbuf])
+        r0 = time_region(lambda i: fs.step(batches[i % nbuf]), max(1, steps_timed // 2), barrier, repeats=3, reduce_max=reduce_max)
+        noupd = {"queries_per_s": n_gpus * B * max(1, steps_timed // 2) / median(r0),
+                 "ms_per_step": median(r0) / max(1, steps_timed // 2) * 1e3,
+                 "what": "ltr_linear_step_f32: the same two launches, W left alone (rounds 1-3 reported this)"}
+
     out = None
     if rank == 0:
         extra = {"timed_regions_s": regions, "steps_per_region": steps_timed}
+        if noupd is not None:
+            extra["step_without_weight_update"] = noupd
         _ = pmc_record(args.workload)
         extra["pmc_counters"] = ("profiles/pmc_<workload>.json (separate rocprofv3 --pmc passes); refused when the kernel "
                                  "sources changed since: stale for %s" % (sorted(PMC_STALE) or "none"))
@@ -826,6 +859,12 @@ def main():
                                                                 " (full lists)" if args.full_lists else ""),
                        "global_batch": n_gpus * B, "list_len": L, "features": F, "loss": kind,
                        "mode": "eager", "parallelism": "dp%d" % n_gpus,
+                       "step": ("synchronous SGD step in one C-ABI call (ltr_linear_sgd_step_f32): fused scorer + loss "
+                                "kernel, cross-query reduction into [dW | db | loss_sum]%s, W -= lr * dW (lr %g) -- "
+                                "examples/01-basic-usage.py:66-75" % (
+                                    ", the step's gradient all-reduce" if dist is not None else
+                                    " with the update riding in it", SGD_LR)) if accum == 1 else
+                               "gradient accumulation (no weight update in the timed region)",
                        "batches_in_rotation": nbuf, "steps_timed": steps_timed, "repeats": 5,
                        "statistic": "median of 5 timed regions",
                        "allreduce_every": accum if dist is not None else None,

@@ -364,6 +364,23 @@ int ltr_linear_step_f32(int kind, float sigma, const float *X, const float *W, c
                         int B, int L, int F, float *loss, float *bucket /* F + 2 */, int accumulate,
                         void *workspace, size_t workspace_bytes, void *overlap /* or NULL */, int slot,
                         void *stream);
+/* One synchronous-SGD step of the reference's training loop in one call -- replaces
+ *   loss = loss_fn(model(xs), ys, n).mean(); optimizer.zero_grad(); loss.backward(); optimizer.step()
+ * with model = torch.nn.Linear(F, 1) and torch.optim.SGD(lr) (examples/01-basic-usage.py:66-75).  The step's
+ * kernels write the bucket [dW (F) | db | loss_sum] (upstream gradient grad_out, NULL = 1 / B; data parallel:
+ * 1 / (B * N)); with an IN-STREAM overlap handle (ltr_overlap_create(..., depth = 0)) the bucket is all-reduced
+ * on `stream` right behind them; then W -= lr * dW and bias -= lr * db IN PLACE.  Step i + 1 scores with the
+ * weights step i's all-reduced gradient produced: the collective is on the critical path, as in every
+ * synchronous data-parallel SGD.  overlap handles with depth > 0 are refused (LTR_ERR_CONFIG).  At one rank
+ * (overlap NULL) the update rides in the reduction kernel: two launches per step. */
+int ltr_linear_sgd_step_f32(int kind, float sigma, const float *X, float *W, float *bias, const void *rel,
+                            int rel_dtype, const int64_t *n, const float *grad_out, int B, int L, int F,
+                            float lr, float *loss, float *bucket /* F + 2 */, void *workspace,
+                            size_t workspace_bytes, void *overlap /* or NULL */, void *stream);
+/* Tests only: an ltr_allreduce_fn that adds `comm` -- a device pointer to `count` floats, "the other rank's
+ * bucket" -- to the buffer on `stream` (ncclFloat32 / ncclSum only). */
+int ltr_debug_fake_allreduce(const void *sendbuf, void *recvbuf, size_t count, int datatype, int op, void *comm,
+                             void *stream);
 
 /* --- fused ReLU-MLP scorer + loss + backward --------------------
  * Replaces the user-side composition `loss_fn(model(xs), ys, n)` + `.backward()` with `model` the

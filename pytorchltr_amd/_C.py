@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("LTR_HIP_LIB") or os.path.join(_HERE, "csrc", "libltr_
 HINGE, DCG_HINGE, LOGISTIC, ARP1, ARP2, NDCG1, NDCG2 = range(7)
 # enum ltr_label_dtype
 LABEL_I64, LABEL_F32, LABEL_I32 = 0, 1, 2
+ERR_CONFIG = -6
 ERR_TIMEOUT = -7
 # ltr_linear_fused_plan (include/ltr_hip.h)
 PLAN_NONE, PLAN_REGISTER_TILE, PLAN_CLUSTER, PLAN_GENERAL, PLAN_PARTS = 0, 1, 2, 3, 4
@@ -67,6 +68,9 @@ SIGNATURES = {
     "ltr_overlap_flush": (_i, [_vp]),
     "ltr_linear_step_f32": (_i, [_i, _f, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _sz,
                                 _vp, _i, _vp]),
+    "ltr_linear_sgd_step_f32": (_i, [_i, _f, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _sz,
+                                    _vp, _vp]),
+    "ltr_debug_fake_allreduce": (_i, [_vp, _vp, _sz, _i, _i, _vp, _vp]),
     "ltr_linear_pairwise_f32": (_i, [_i, _f, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i,
                                      _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ltr_linear_partials_f32": (_i, [_i, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i,

@@ -266,6 +266,17 @@ class RcclOverlap:
             1 if accumulate else 0, workspace.data_ptr(), workspace.numel() * workspace.element_size(),
             self.handle, k, st))
 
+    def sgd_step(self, kind, sigma, X, W, bias, rel, rel_dtype, n, grad_out, B, L, F, lr, loss, workspace):
+        """One synchronous-SGD step through ltr_linear_sgd_step_f32 (in-stream handles only): kernels, the step's
+        all-reduce behind them on the same stream, then W -= lr * dW, bias -= lr * db -- the next step scores with
+        weights that waited for this step's collective (examples/01-basic-usage.py:72-75, sharded)."""
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        self._C.check(self.lib.ltr_linear_sgd_step_f32(
+            kind, sigma, X.data_ptr(), W.data_ptr(), bias.data_ptr(), rel.data_ptr(), rel_dtype, n.data_ptr(),
+            None if grad_out is None else grad_out.data_ptr(), B, L, F, float(lr), loss.data_ptr(),
+            self.buckets[0].data_ptr(), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+            self.handle, st))
+
     def result(self, i):
         """Step i's summed bucket; the current stream is made to wait for its all-reduce."""
         k = i % max(1, self.depth)

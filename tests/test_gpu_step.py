@@ -1,0 +1,161 @@
+"""GPU tier: the data-parallel step entry points against the oracle (ltr_linear_step_f32 and the
+overlap handle had only HIP-against-HIP checks inside a bench subprocess).
+
+A second rank is played by `ltr_debug_fake_allreduce`, an ltr_allreduce_fn that adds a known bucket -- the
+step of the OTHER shard, computed beforehand -- on the stream it is given: the all-reduced bucket of shard 1
+must then be the gradient of the mean loss over the CONCATENATED batch, which the oracle computes directly
+(reference step: loss_fn(Linear(F,1)(xs), ys, n).mean().backward(), examples/01-basic-usage.py:66-75, sharded
+by queries as SURVEY.md 8(e) prescribes).  In-stream handle (depth 0), helper-thread handle (depth 2, three
+rotating slots' worth of steps), and the synchronous-SGD step ltr_linear_sgd_step_f32 over several updates.
+Tolerances: gradients 2e-5 of the largest entry + 1e-6, loss sums rtol 1e-5 (fp32 sums in another order)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ltr_oracle as O
+from tests.conftest import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _shards(B1, B2, L, F, seed):
+    s, y, n, X, W, b = synth(B1 + B2, L, seed, F=F)
+    return (X, y, n, W, b), (X[:B1], y[:B1], n[:B1]), (X[B1:], y[B1:], n[B1:])
+
+
+def _oracle(kind, X, W, b, y, n):
+    B = X.shape[0]
+    loss, _, dW, db = O.linear_pairwise(kind, X.numpy(), W.numpy(), float(b[0]), y.numpy(), n.numpy(),
+                                        np.full(B, 1.0 / B))
+    return loss, dW, db
+
+
+def _step(lib, _C, kind_id, Xd, Wd, bd, yd, nd, go, lossv, bucket, ws, handle, slot):
+    B, L, F = Xd.shape
+    _C.check(lib.ltr_linear_step_f32(kind_id, 1.0, Xd.data_ptr(), Wd.data_ptr(), bd.data_ptr(), yd.data_ptr(),
+                                     _C.LABEL_I64, nd.data_ptr(), go.data_ptr(), B, L, F, lossv.data_ptr(),
+                                     bucket.data_ptr(), 0, ws.data_ptr(), ws.numel() * 4, handle, slot,
+                                     _C.stream_of(Xd)))
+
+
+@pytest.mark.parametrize("shape", [("hinge", 70, 42, 128, 136), ("ndcg2", 33, 31, 100, 64), ("dcg_hinge", 20, 12, 1000, 220),
+                                   ("logistic", 40, 30, 512, 700)])
+@pytest.mark.parametrize("depth", [0, 2])
+def test_step_with_the_other_ranks_bucket_added_in_the_allreduce(shape, depth):
+    from pytorchltr_amd import _C
+    lib = _C.lib()
+    dev = _dev()
+    kind, B1, B2, L, F = shape
+    kind_id = getattr(_C, kind.upper())
+    (X, y, n, W, b), (X1, y1, n1), (X2, y2, n2) = _shards(B1, B2, L, F, 11)
+    Wd, bd = W.to(dev), b.to(dev)
+    go1 = torch.full((B1,), 1.0 / (B1 + B2), device=dev)
+    go2 = torch.full((B2,), 1.0 / (B1 + B2), device=dev)
+    d1 = [t.to(dev) for t in (X1, y1, n1)]
+    d2 = [t.to(dev) for t in (X2, y2, n2)]
+    ws = torch.empty(max(lib.ltr_linear_workspace_bytes(B1, L, F), lib.ltr_linear_workspace_bytes(B2, L, F)) // 4 + 64,
+                     device=dev)
+    loss1, loss2 = torch.empty(B1, device=dev), torch.empty(B2, device=dev)
+    other = torch.zeros(F + 2, device=dev)
+    _step(lib, _C, kind_id, d2[0], Wd, bd, d2[1], d2[2], go2, loss2, other, ws, None, 0)     # "rank 1"
+    torch.cuda.synchronize()
+    want_loss, want_dW, want_db = _oracle(kind, X, W, b, y, n)
+    fn = ctypes.cast(lib.ltr_debug_fake_allreduce, ctypes.c_void_p)
+    handle = ctypes.c_void_p(None)
+    _C.check(lib.ltr_overlap_create(fn, ctypes.c_void_p(other.data_ptr()), depth, ctypes.byref(handle)))
+    try:
+        buckets = [torch.zeros(F + 2, device=dev) for _ in range(max(1, depth))]
+        wss = [torch.empty_like(ws) for _ in range(max(1, depth))]
+        for i in range(5 if depth else 2):
+            k = i % max(1, depth)
+            _step(lib, _C, kind_id, d1[0], Wd, bd, d1[1], d1[2], go1, loss1, buckets[k], wss[k], handle, k)
+            # (the stream waits for this slot's all-reduce -- on the helper's side stream when depth > 0)
+            _C.check(lib.ltr_overlap_wait(handle, k, _C.stream_of(d1[0])))
+            torch.cuda.synchronize()
+            got = buckets[k].cpu().numpy()
+            tol = 2e-5 * max(1.0, float(np.max(np.abs(want_dW)))) + 1e-6
+            assert np.max(np.abs(got[:F] - want_dW)) < tol, (i, k)
+            assert abs(got[F] - want_db) < tol, (i, k)
+            assert np.isclose(got[F + 1], float(np.sum(want_loss)), rtol=2e-5, atol=1e-4), (i, k)
+        _C.check(lib.ltr_overlap_flush(handle))
+    finally:
+        lib.ltr_overlap_destroy(handle)
+    _C.device_status()
+
+
+@pytest.mark.parametrize("shape", [("hinge", 96, 0, 128, 136), ("hinge", 70, 42, 128, 136), ("dcg_hinge", 20, 12, 1000, 220),
+                                   ("ndcg2", 64, 0, 128, 136)])
+def test_sgd_step_follows_the_oracles_trajectory(shape):
+    """ltr_linear_sgd_step_f32 over four updates: W_{k+1} = W_k - lr * d mean loss / dW at W_k, against the same
+    recursion on the oracle (fp64 gradients, fp32 weights); with a second shard added through the in-stream
+    handle the gradient is the concatenated batch's, and the update waits for it."""
+    from pytorchltr_amd import _C
+    lib = _C.lib()
+    dev = _dev()
+    kind, B1, B2, L, F = shape
+    kind_id = getattr(_C, kind.upper())
+    (X, y, n, W, b), (X1, y1, n1), (X2, y2, n2) = _shards(B1, B2, L, F, 5)
+    lr = 0.05
+    Wd, bd = W.clone().to(dev), b.clone().to(dev)
+    d1 = [t.to(dev) for t in (X1, y1, n1)]
+    go1 = torch.full((B1,), 1.0 / (B1 + B2), device=dev)
+    ws = torch.empty(lib.ltr_linear_workspace_bytes(max(B1, B2, 1), L, F) // 4 + 64, device=dev)
+    loss1 = torch.empty(B1, device=dev)
+    bucket = torch.zeros(F + 2, device=dev)
+    handle = ctypes.c_void_p(None)
+    other = torch.zeros(F + 2, device=dev)
+    if B2:
+        d2 = [t.to(dev) for t in (X2, y2, n2)]
+        go2 = torch.full((B2,), 1.0 / (B1 + B2), device=dev)
+        loss2 = torch.empty(B2, device=dev)
+        fn = ctypes.cast(lib.ltr_debug_fake_allreduce, ctypes.c_void_p)
+        _C.check(lib.ltr_overlap_create(fn, ctypes.c_void_p(other.data_ptr()), 0, ctypes.byref(handle)))
+    Wh, bh = W.clone(), b.clone()
+    try:
+        for k in range(4):
+            if B2:      # "rank 1" computes its bucket with the CURRENT weights (no update of its own: one model)
+                _step(lib, _C, kind_id, d2[0], Wd, bd, d2[1], d2[2], go2, loss2, other, ws, None, 0)
+            _C.check(lib.ltr_linear_sgd_step_f32(kind_id, 1.0, d1[0].data_ptr(), Wd.data_ptr(), bd.data_ptr(),
+                                                 d1[1].data_ptr(), _C.LABEL_I64, d1[2].data_ptr(), go1.data_ptr(),
+                                                 B1, L, F, lr, loss1.data_ptr(), bucket.data_ptr(), ws.data_ptr(),
+                                                 ws.numel() * 4, handle if B2 else None, _C.stream_of(d1[0])))
+            want_loss, want_dW, want_db = _oracle(kind, X, Wh, bh, y, n)
+            torch.cuda.synchronize()
+            got = bucket.cpu().numpy()
+            tol = 5e-5 * max(1.0, float(np.max(np.abs(want_dW)))) + 1e-6
+            assert np.max(np.abs(got[:F] - want_dW)) < tol, k
+            Wh = (Wh.double() - lr * torch.from_numpy(want_dW)).float()
+            bh = (bh.double() - lr * want_db).float()
+            assert np.allclose(Wd.cpu().numpy(), Wh.numpy(), rtol=1e-4, atol=1e-5), k
+            assert np.allclose(bd.cpu().numpy(), bh.numpy(), rtol=1e-4, atol=1e-5), k
+    finally:
+        if B2:
+            lib.ltr_overlap_destroy(handle)
+    _C.device_status()
+
+
+def test_sgd_step_refuses_a_deferred_allreduce():
+    from pytorchltr_amd import _C
+    lib = _C.lib()
+    dev = _dev()
+    s, y, n, X, W, b = synth(8, 16, 3, F=8)
+    t = [v.to(dev) for v in (X, W, b, y, n)]
+    other = torch.zeros(10, device=dev)
+    handle = ctypes.c_void_p(None)
+    fn = ctypes.cast(lib.ltr_debug_fake_allreduce, ctypes.c_void_p)
+    _C.check(lib.ltr_overlap_create(fn, ctypes.c_void_p(other.data_ptr()), 2, ctypes.byref(handle)))
+    try:
+        ws = torch.empty(lib.ltr_linear_workspace_bytes(8, 16, 8) // 4 + 64, device=dev)
+        rc = lib.ltr_linear_sgd_step_f32(_C.HINGE, 1.0, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(),
+                                         _C.LABEL_I64, t[4].data_ptr(), None, 8, 16, 8, 0.1, torch.empty(8, device=dev).data_ptr(),
+                                         other.data_ptr(), ws.data_ptr(), ws.numel() * 4, handle, _C.stream_of(t[0]))
+        assert rc == _C.ERR_CONFIG
+    finally:
+        lib.ltr_overlap_destroy(handle)
