@@ -674,18 +674,35 @@ def main():
         # alone is 22 us), a side stream + events 32-34 (a wait on a just-recorded event costs the host
         # 6.5 us on ROCm 7.2, twice per step, helper thread or not) -- against 14.9 in-stream, where the
         # collective's own latency stays on the stream.
-        from pytorchltr_amd.distributed import OverlappedBucketAllReduce, RcclOverlap
-        mode = os.environ.get("LTR_BENCH_ALLREDUCE", "instream")
-        raw = RcclOverlap(F, count=B, device=dev, depth=(0 if mode == "instream" else 2)) if mode != "c10d" else None
+        from pytorchltr_amd.distributed import MailboxOverlap, OverlappedBucketAllReduce, RcclOverlap
+        # the collective of the step: "mailbox" (default: the hand-written small-message all-reduce over HIP-IPC
+        # mapped peer mailboxes, include/ltr_hip.h; falls back to "instream" on every rank when it cannot be set up
+        # or its self-check against torch.distributed disagrees), "instream" (one ncclAllReduce on the step's stream,
+        # RCCL communicator of its own), "overlap" (RCCL on a side stream, delayed gradient), "c10d"
+        mode = os.environ.get("LTR_BENCH_ALLREDUCE", "mailbox")
+        raw = None
+        if mode == "mailbox":
+            raw = MailboxOverlap(F, count=B, device=dev)
+            if not raw.ok:
+                sys.stderr.write("[bench] mailbox all-reduce unavailable (%s): RCCL in-stream\n" % raw.why)
+                raw.close()
+                raw, mode = None, "instream"
+        if raw is None and mode != "c10d":
+            raw = RcclOverlap(F, count=B, device=dev, depth=(0 if mode == "instream" else 2))
         if raw is not None and raw.ok:
             red = raw
-            allreduce_impl = ("ltr_linear_step_f32 + %s handle: ncclAllReduce %s (RCCL communicator of its own)" % (
-                ("in-stream", "on the step's stream behind its kernels") if mode == "instream" else
-                ("overlap", "on a side stream under the next step")))
+            if mode == "mailbox":
+                allreduce_impl = ("ltr_linear_sgd_step_f32 + mailbox all-reduce: one kernel per rank stores the bucket's tagged "
+                                  "granules into every peer's HIP-IPC-mapped mailbox, adds the arrivals in rank order and applies "
+                                  "the weight update (no collective library in the step)")
+            else:
+                allreduce_impl = ("ltr_linear_step_f32 + %s handle: ncclAllReduce %s (RCCL communicator of its own)" % (
+                    ("in-stream", "on the step's stream behind its kernels") if mode == "instream" else
+                    ("overlap", "on a side stream under the next step")))
 
             def step(i):
                 b = batches[i % nbuf]
-                if mode == "instream":      # synchronous SGD: kernels, all-reduce, W -= lr * dW -- one C-ABI call
+                if mode in ("instream", "mailbox"):      # synchronous SGD: kernels, all-reduce, W -= lr * dW -- one C-ABI call
                     raw.sgd_step(fs.kind_id, 1.0, b["X"], fs.W, fs.bias, b["rel"], _C.LABEL_I64, b["n"], fs.go, B, L, F,
                                  SGD_LR, fs.lossv, fs.part)
                 else:

@@ -377,6 +377,22 @@ int ltr_linear_sgd_step_f32(int kind, float sigma, const float *X, float *W, flo
                             int rel_dtype, const int64_t *n, const float *grad_out, int B, int L, int F,
                             float lr, float *loss, float *bucket /* F + 2 */, void *workspace,
                             size_t workspace_bytes, void *overlap /* or NULL */, void *stream);
+/* Mailbox all-reduce: the < 3 KB gradient bucket of a data-parallel step summed over the ranks of ONE node by a
+ * single small kernel per rank instead of a collective library (one process per GPU; no counterpart in the
+ * reference, which is single-process).  Every rank owns a mailbox of 8-byte {tag, value} granules in fine-grained
+ * device memory, mapped into its peers with hipIpcGetMemHandle / hipIpcOpenMemHandle; an all-reduce stores the
+ * rank's granules into every peer's mailbox (over xGMI) and adds what arrives in its own IN RANK ORDER, so all
+ * ranks obtain bit-identical sums.  Set-up: every rank calls ltr_mailbox_create (its IPC handle comes back in 64
+ * bytes), the callers gather the handles (any transport), every rank calls ltr_mailbox_connect with all of them
+ * in rank order.  ltr_mailbox_allreduce has ncclAllReduce's signature (ncclFloat32 / ncclSum only; comm = the
+ * handle; count <= count_max), so it can be given to ltr_overlap_create(..., depth = 0); ltr_linear_sgd_step_f32
+ * then applies the weight update inside the same kernel.  A rank that never shows up turns into NaN sums and
+ * LTR_ERR_TIMEOUT in the device status, not a hang.  world <= 16. */
+int ltr_mailbox_create(int rank, int world, int count_max, void **handle, void *ipc_handle_out /* 64 bytes */);
+int ltr_mailbox_connect(void *handle, const void *all_ipc_handles /* world x 64 bytes, rank order */);
+int ltr_mailbox_destroy(void *handle);
+int ltr_mailbox_allreduce(const void *sendbuf, void *recvbuf, size_t count, int datatype, int op, void *comm,
+                          void *stream);
 /* Tests only: an ltr_allreduce_fn that adds `comm` -- a device pointer to `count` floats, "the other rank's
  * bucket" -- to the buffer on `stream` (ncclFloat32 / ncclSum only). */
 int ltr_debug_fake_allreduce(const void *sendbuf, void *recvbuf, size_t count, int datatype, int op, void *comm,

@@ -5,6 +5,7 @@
 #include <condition_variable>
 #include <deque>
 #include <mutex>
+#include <string.h>
 #include <thread>
 
 #include "ltr_common.inc"

@@ -299,3 +299,145 @@ class RcclOverlap:
                 pass
             self.comm = ctypes.c_void_p(None)
         self.ok = False
+
+
+# ---------------------------------------------------------------------------------------------
+# The same per-step exchange without ANY collective library in the step: the mailbox all-reduce of the C ABI
+# (include/ltr_hip.h: ltr_mailbox_*): peers' mailboxes mapped through HIP IPC, one small kernel per rank stores
+# the bucket's tagged granules into every peer and adds what arrives in rank order -- bit-identical sums on all
+# ranks, one hop over xGMI, and inside ltr_linear_sgd_step_f32 the weight update rides in the same kernel.
+# ---------------------------------------------------------------------------------------------
+class MailboxOverlap:
+    """In-stream gradient all-reduce of the fused step through the mailbox all-reduce.
+
+        mb = MailboxOverlap(F, count=B, device=dev)       # needs an initialised process group (any backend)
+        if mb.ok:
+            for batch in batches:
+                mb.sgd_step(kind, sigma, X, W, bias, rel, rel_dtype, n, grad_out, B, L, F, lr, loss, workspace)
+        mb.close()
+
+    `ok` is False -- on EVERY rank -- when the mailboxes could not be set up (IPC handle not obtainable or not
+    mappable, e.g. ranks on different nodes) or the self-check against torch.distributed disagrees; callers then
+    fall back to RcclOverlap / torch.distributed.  Interface as RcclOverlap(depth=0)."""
+
+    def __init__(self, F, count, device, group=None):
+        from . import _C
+        self.F, self.depth, self.device = int(F), 0, torch.device(device)
+        self.lib = _C.lib()
+        self._C = _C
+        self.handle = ctypes.c_void_p(None)       # overlap handle
+        self.mbox = ctypes.c_void_p(None)         # mailbox handle (= comm of the overlap handle)
+        self.ok = False
+        self.why = "not built"
+        self.group = group
+        self.buckets = [torch.zeros(self.F + 3, dtype=torch.float32, device=self.device)]
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        cnt = torch.tensor([float(count)], dtype=torch.float32, device=self.device)
+        if dist.is_initialized():
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+        self.global_count = float(cnt.item())
+        self.buckets[0][self.F + 2:self.F + 3].copy_(cnt)
+        if world > 16:
+            self.why = "more than 16 ranks"
+            return
+        blob = ctypes.create_string_buffer(64)
+        with torch.cuda.device(self.device):
+            rc = self.lib.ltr_mailbox_create(rank, world, self.F + 2, ctypes.byref(self.mbox), blob)
+        if not self._all_agree(1 if rc == 0 else 0):
+            self.why = "ltr_mailbox_create returned %d (hipIpcGetMemHandle?)" % rc
+            return
+        handles = [None] * world
+        if dist.is_initialized() and world > 1:
+            dist.all_gather_object(handles, blob.raw, group=group)
+        else:
+            handles = [blob.raw]
+        allh = ctypes.create_string_buffer(b"".join(handles), 64 * world)
+        with torch.cuda.device(self.device):
+            rc = self.lib.ltr_mailbox_connect(self.mbox, allh)
+        if not self._all_agree(1 if rc == 0 else 0):
+            self.why = "ltr_mailbox_connect returned %d (hipIpcOpenMemHandle: ranks on one node, one process per GPU?)" % rc
+            return
+        fn = ctypes.cast(self.lib.ltr_mailbox_allreduce, ctypes.c_void_p)
+        with torch.cuda.device(self.device):
+            rc = self.lib.ltr_overlap_create(fn, self.mbox, 0, ctypes.byref(self.handle))
+        if not self._all_agree(1 if rc == 0 else 0):
+            self.why = "ltr_overlap_create returned %d" % rc
+            return
+        self.ok = bool(self._all_agree(1 if self._self_check() else 0))
+        self.why = "ok" if self.ok else "self-check against torch.distributed failed: %s" % getattr(self, "_check_note", "?")
+
+    def _all_agree(self, flag):
+        if not dist.is_initialized():
+            return int(flag)
+        t = torch.tensor([int(flag)], dtype=torch.int32, device=self.device)
+        if dist.get_backend(self.group) == "gloo":
+            t = t.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return int(t.item())
+
+    def allreduce_(self, vec):
+        """In-place sum of a float32 device vector of at most F + 2 elements over the ranks (current stream)."""
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.lib.ltr_mailbox_allreduce(vec.data_ptr(), vec.data_ptr(), vec.numel(), 7, 0, self.mbox, st)
+        if rc != 0:
+            raise RuntimeError("ltr_mailbox_allreduce failed")
+        return vec
+
+    def _self_check(self):
+        try:
+            rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+            ok = True
+            for rep in range(3):             # both parities, and once more
+                v = (torch.arange(self.F + 2, dtype=torch.float32, device=self.device) + 1.0 + rep) * float(rank + 1) * 0.37
+                want = v.clone()
+                if dist.is_initialized():
+                    w = want.cpu() if dist.get_backend(self.group) == "gloo" else want
+                    dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group)
+                    want = w.to(self.device)
+                self.allreduce_(v)
+                torch.cuda.synchronize(self.device)
+                # (the mailbox adds in rank order, the library in its own: equal to a few ulps, not bit for bit)
+                ok = ok and bool(torch.allclose(v, want, rtol=1e-5, atol=1e-6))
+                self._check_note = "max abs diff %g" % float((v - want).abs().max())
+            return ok and self._C.lib().ltr_device_status(0) == 0
+        except Exception as exc:  # pragma: no cover - depends on the runtime
+            self._check_note = repr(exc)
+            return False
+
+    def sgd_step(self, kind, sigma, X, W, bias, rel, rel_dtype, n, grad_out, B, L, F, lr, loss, workspace):
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        self._C.check(self.lib.ltr_linear_sgd_step_f32(
+            kind, sigma, X.data_ptr(), W.data_ptr(), bias.data_ptr(), rel.data_ptr(), rel_dtype, n.data_ptr(),
+            None if grad_out is None else grad_out.data_ptr(), B, L, F, float(lr), loss.data_ptr(),
+            self.buckets[0].data_ptr(), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+            self.handle, st))
+
+    def step(self, i, kind, sigma, X, W, bias, rel, rel_dtype, n, grad_out, B, L, F, loss, workspace, accumulate=False):
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        self._C.check(self.lib.ltr_linear_step_f32(
+            kind, sigma, X.data_ptr(), W.data_ptr(), bias.data_ptr(), rel.data_ptr(), rel_dtype, n.data_ptr(),
+            None if grad_out is None else grad_out.data_ptr(), B, L, F, loss.data_ptr(), self.buckets[0].data_ptr(),
+            1 if accumulate else 0, workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+            self.handle, 0, st))
+
+    def result(self, i=0):
+        return self.buckets[0]
+
+    def flush(self):
+        torch.cuda.synchronize(self.device)
+
+    def close(self):
+        if self.handle:
+            self.lib.ltr_overlap_destroy(self.handle)
+            self.handle = ctypes.c_void_p(None)
+        if self.mbox:
+            if dist.is_initialized():
+                try:
+                    torch.cuda.synchronize(self.device)
+                    dist.barrier(group=self.group)       # nobody unmaps a mailbox a peer may still write
+                except Exception:  # pragma: no cover
+                    pass
+            self.lib.ltr_mailbox_destroy(self.mbox)
+            self.mbox = ctypes.c_void_p(None)
+        self.ok = False

@@ -1,0 +1,91 @@
+"""Worker of tests/test_gpu_mailbox.py: one of WORLD_SIZE processes, all on cuda:0 (HIP IPC between processes on
+one device), rendezvous over gloo.  Prints one JSON line."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    from pytorchltr_amd import _C
+    from pytorchltr_amd.distributed import MailboxOverlap, shard_bounds
+    from oracle import ltr_oracle as O
+    from tests.conftest import synth
+    out = {"rank": rank}
+    B, L, F, kind = 96, 128, 136, "hinge"
+    lo, hi = shard_bounds(B, rank, world)
+    mb = MailboxOverlap(F, count=hi - lo, device=dev)
+    out["ok"], out["why"] = bool(mb.ok), mb.why
+    if not mb.ok:
+        print(json.dumps(out), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    # ---- plain all-reduces: known vectors, uneven arrival, both parities many times over ----
+    busy = torch.randn(2048, 2048, device=dev)
+    bad = 0
+    same = True
+    for it in range(60):
+        g = torch.Generator().manual_seed(1000 * it)
+        vecs = [torch.randn(F + 2, generator=g) * (r + 1) for r in range(world)]
+        want = vecs[0].clone()
+        for r in range(1, world):
+            want = want + vecs[r]                       # rank order, fp32: what the kernel does
+        v = vecs[rank].to(dev)
+        if (it + rank) % 3 == 0:                        # this rank shows up late
+            for _ in range(3):
+                busy = torch.tanh(busy @ busy) * 0.01
+        if it % 7 == rank:
+            time.sleep(0.002)
+        mb.allreduce_(v)
+        torch.cuda.synchronize()
+        got = v.cpu()
+        if not torch.equal(got, want):
+            bad += 1
+        gathered = [None] * world
+        dist.all_gather_object(gathered, got.numpy().tobytes())
+        same = same and all(g_ == gathered[0] for g_ in gathered)
+    out["allreduce_mismatches"] = bad
+    out["bit_identical_across_ranks"] = bool(same)
+    # ---- synchronous SGD over the shards: the trajectory of the oracle on the whole batch ----
+    s, y, n, X, W, b = synth(B, L, 21, F=F)
+    Xd, yd, nd = X[lo:hi].to(dev), y[lo:hi].to(dev), n[lo:hi].to(dev)
+    Wd, bd = W.clone().to(dev), b.clone().to(dev)
+    go = torch.full((hi - lo,), 1.0 / B, device=dev)
+    lib = _C.lib()
+    ws = torch.empty(lib.ltr_linear_workspace_bytes(hi - lo, L, F) // 4 + 64, device=dev)
+    loss = torch.empty(hi - lo, device=dev)
+    lr = 0.05
+    Wh, bh = W.clone(), b.clone()
+    traj_ok = True
+    for k in range(4):
+        mb.sgd_step(_C.HINGE, 1.0, Xd, Wd, bd, yd, _C.LABEL_I64, nd, go, hi - lo, L, F, lr, loss, ws)
+        _, _, dW, db = O.linear_pairwise(kind, X.numpy(), Wh.numpy(), float(bh[0]), y.numpy(), n.numpy(), np.full(B, 1.0 / B))
+        Wh = (Wh.double() - lr * torch.from_numpy(dW)).float()
+        bh = (bh.double() - lr * db).float()
+        torch.cuda.synchronize()
+        traj_ok = traj_ok and bool(np.allclose(Wd.cpu().numpy(), Wh.numpy(), rtol=1e-4, atol=1e-5))
+    out["sgd_trajectory_ok"] = bool(traj_ok)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, Wd.cpu().numpy().tobytes())
+    out["weights_identical_across_ranks"] = all(g_ == gathered[0] for g_ in gathered)
+    out["status"] = int(lib.ltr_device_status(0))
+    mb.close()
+    print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
