@@ -622,7 +622,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # (LTR_BENCH_BACKEND=gloo with every rank on LOCAL_RANK 0: the N > 1 code path -- mailbox all-reduce, SGD step,
+        # max-over-ranks timing -- run functionally by several processes on ONE GPU; tests/test_gpu_bench.py)
+        backend = os.environ.get("LTR_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     n_gpus = world
     if dist is not None:
         # ProcessGroupNCCL's watchdog thread polls HIP events; an event query while another

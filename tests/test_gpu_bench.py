@@ -78,3 +78,30 @@ def test_forced_process_group_accumulates_and_allreduces():
 def test_shard_mode_splits_the_global_batch():
     out = _run(["--workload", "c4", "--shard"])
     assert out["scaling"] == "strong" and out["config"]["global_batch"] == 256
+
+
+def test_two_ranks_on_one_gpu_run_the_data_parallel_step_with_the_mailbox_allreduce():
+    """`bench.py --gpus 2` as the driver launches it, except that both ranks sit on cuda:0 and rendezvous over gloo
+    (RCCL refuses two ranks on one device): the whole N > 1 path -- ltr_linear_sgd_step_f32 with the mailbox
+    all-reduce between the two processes, the weight update, barrier + max-over-ranks timing, rank 0's JSON line --
+    runs for real; only the numbers mean nothing (two processes share one GPU)."""
+    port = 29300 + os.getpid() % 300
+    procs = []
+    for r in range(2):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "WORLD_SIZE": "2", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "LTR_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20",
+                                       "--warmup", "5", "--no-extra", "--no-cpu-baseline"], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = []
+    for p in procs:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, se.decode()[-3000:]
+        outs.append(so.decode())
+    lines = [ln for ln in outs[0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not [ln for ln in outs[1].splitlines() if ln.startswith("{")]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2048
+    assert "mailbox" in out["config"]["allreduce"], out["config"]["allreduce"]
+    assert out["config"]["allreduce_every"] == 1 and out["value"] > 1e5
