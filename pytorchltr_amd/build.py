@@ -55,10 +55,18 @@ def build_extension(force=False, verbose=False, extra_flags=(), lib_path=None):
             print(" ".join(cmd), flush=True)
         jobs.append((cmd, subprocess.Popen(cmd), obj))
     objs = []
-    for cmd, proc, obj in jobs:
-        if proc.wait() != 0:
-            raise subprocess.CalledProcessError(proc.returncode, cmd)
+    failed = None
+    for cmd, proc, obj in jobs:                  # every compiler is waited for, whatever the others returned
+        if proc.wait() != 0 and failed is None:
+            failed = (proc.returncode, cmd)
         objs.append(obj)
+    if failed is not None:
+        for obj in objs:                         # (no stale object may be linked by a later, partial build)
+            try:
+                os.remove(obj)
+            except OSError:
+                pass
+        raise subprocess.CalledProcessError(*failed)
     link = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc", "-pthread", "-o", lib_path] + objs
     if verbose:
         print(" ".join(link), flush=True)

@@ -172,6 +172,13 @@ class RcclOverlap:
     depth = 0: in-stream mode -- the all-reduce is enqueued on the step's own stream behind its kernels (no
     side stream, no helper thread: one ncclAllReduce call of host cost per step).
 
+    While a step() is in flight no OTHER collective may be issued on this device (torch.distributed's communicator
+    and this one would be used from two threads at once -- with depth > 0 the handle's helper thread enqueues the
+    all-reduce -- and RCCL orders collectives per communicator only: different ranks could interleave them
+    differently); call flush() first.  The RCCL kernel also takes CU slots: a persistent-workgroup kernel (the parts
+    kernel) sized for the whole chip then runs with part of its grid not resident and makes progress through its
+    tickets, more slowly.
+
     `ok` is False when the raw communicator could not be built on EVERY rank (library or symbol missing,
     ncclCommInitRank failing, or the self-check against torch.distributed disagreeing); callers then use
     OverlappedBucketAllReduce instead.  All ranks take the same decision.

@@ -251,7 +251,7 @@ class _LinearScoreFunction(torch.autograd.Function):
                                                         B, L, F, _C.ptr(scores), _C.stream_of(X)))
         # (the layer's input needs a gradient only when it is not the feature batch itself -- a hidden
         # layer's output: the weight is kept for grad_xs = grad_scores (x) weight in that case)
-        ctx.xs_grad = bool(torch.is_tensor(xs) and xs.requires_grad)
+        ctx.xs_grad = bool(ctx.needs_input_grad[0])
         ctx.save_for_backward(X, nn if nn is not None else torch.empty(0, device=X.device),
                               W if ctx.xs_grad else torch.empty(0, device=X.device))
         ctx.xs_shape = xs.shape
@@ -300,10 +300,13 @@ class LinearScorer(torch.nn.Module):
             torch.nn.init.uniform_(self.bias, -bound, bound)
 
     def forward(self, xs, n=None):
+        if not (torch.is_tensor(xs) and xs.dim() == 3 and xs.is_cuda):
+            # not a (B, L, F) feature batch on the device (a value head, a gate, a 2-D input ...): the plain layer
+            return torch.nn.functional.linear(xs, self.weight, self.bias)
         return _LinearScoreFunction.apply(xs, self.weight, self.bias, n)
 
 
-def use_linear_scorer(model):
+def use_linear_scorer(model, predicate=None):
     """The one-liner for an existing training script: every ``torch.nn.Linear(F, 1)`` inside `model`
     (or `model` itself) is replaced by a :class:`LinearScorer` that SHARES its parameters -- same
     ``state_dict`` keys, same Parameter objects, so optimisers, checkpoints and ``model.parameters()``
@@ -311,7 +314,8 @@ def use_linear_scorer(model):
     one-column GEMM (304 us -> 46 us per step at the C2 shape; reference user code:
     examples/01-basic-usage.py:36,66-75).  Returns the model (a new module when `model` itself was the
     Linear layer).  Only applied where the layer's input is the (B, L, F) feature batch, i.e. where the
-    user wrote ``Linear(F, 1)`` as the scorer."""
+    user wrote ``Linear(F, 1)`` as the scorer: `predicate(name, module) -> bool` restricts the replacement (default: every
+    ``Linear(*, 1)``); a converted layer that is fed anything but a 3-D device tensor falls back to ``F.linear``."""
     def convert(lin):
         sc = LinearScorer(lin.in_features, bias=lin.bias is not None)
         sc.weight = lin.weight                      # the same Parameter objects
@@ -323,12 +327,13 @@ def use_linear_scorer(model):
         return isinstance(m, torch.nn.Linear) and m.out_features == 1
 
     if is_scorer(model):
-        return convert(model)
+        return convert(model) if (predicate is None or predicate("", model)) else model
     for name, child in list(model.named_children()):
         if is_scorer(child):
-            setattr(model, name, convert(child))
+            if predicate is None or predicate(name, child):
+                setattr(model, name, convert(child))
         else:
-            use_linear_scorer(child)
+            use_linear_scorer(child, predicate)
     return model
 
 

@@ -158,3 +158,31 @@ def test_use_linear_scorer_swaps_the_layer_and_keeps_the_parameters():
     lin.bias.grad = None
     loss_fn(lin(X), y, n).mean().backward()
     assert torch.allclose(g1, lin.weight.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_use_linear_scorer_leaves_other_one_column_layers_usable():
+    """use_linear_scorer swaps every Linear(*, 1); a layer that is NOT fed the (B, L, F) feature batch -- a
+    value head on a 2-D input -- must keep working (it falls back to F.linear), and a predicate can keep it out of
+    the swap altogether.  Reference user code: examples/01-basic-usage.py:36."""
+    from pytorchltr_amd.fused import LinearScorer, use_linear_scorer
+    dev = torch.device("cuda:0")
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.scorer = torch.nn.Linear(24, 1)
+            self.value_head = torch.nn.Linear(8, 1)
+
+    net = Net().to(dev)
+    ref_w = net.value_head.weight.detach().clone()
+    use_linear_scorer(net)
+    assert isinstance(net.scorer, LinearScorer) and isinstance(net.value_head, LinearScorer)
+    h = torch.randn(5, 8, device=dev, requires_grad=True)
+    out = net.value_head(h)                                   # 2-D input: the plain layer
+    assert out.shape == (5, 1)
+    assert torch.allclose(out, h @ ref_w.t() + net.value_head.bias)
+    out.sum().backward()
+    assert h.grad is not None and net.value_head.weight.grad is not None
+    net2 = Net().to(dev)
+    use_linear_scorer(net2, predicate=lambda name, m: name == "scorer")
+    assert isinstance(net2.scorer, LinearScorer) and isinstance(net2.value_head, torch.nn.Linear)
