@@ -83,6 +83,9 @@ int ltr_max_list_len_f64(void);
 int ltr_device_status(int clear);
 /* Tests only: != 0 makes every in-launch wait of the multi-workgroup kernels give up at once. */
 void ltr_debug_force_timeout(int on);
+/* Tests only: != 0 lets the parts kernel (below) take every shape it CAN take instead of the shapes where it was
+ * measured to pay (LTR_PARTS_ALL=1 in the environment does the same for a whole process); returns the old value. */
+int ltr_debug_parts_all(int on);
 /*
  * Exchange areas.  The fused-scorer kernels that spread a query over several workgroups (the parts kernel
  * behind ltr_linear_partials_f32 / ltr_linear_pairwise_f32 / ltr_linear_step_f32 for long lists and wide rows)

@@ -31,6 +31,7 @@ SIGNATURES = {
     "ltr_max_list_len_f64": (_i, []),
     "ltr_device_status": (_i, [_i]),
     "ltr_debug_force_timeout": (None, [_i]),
+    "ltr_debug_parts_all": (_i, [_i]),
     "ltr_exchange_release": (_i, []),
     "ltr_debug_set_exchange_tag": (_i, [_vp, ctypes.c_uint32]),
     "ltr_debug_stream_probe_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -184,10 +184,21 @@ def test_fused_plan_for_the_baseline_shapes():
     assert lib.ltr_linear_fused_plan(_C.HINGE, 512, 512, 220) == _C.PLAN_GENERAL             # narrow rows
     assert lib.ltr_linear_fused_plan(_C.HINGE, 64, 512, 700) == _C.PLAN_CLUSTER              # C5 shard of 8 GPUs
     assert lib.ltr_linear_fused_plan(_C.DCG_HINGE, 32, 1000, 220) == _C.PLAN_CLUSTER         # C4 shard of 8 GPUs
-    assert lib.ltr_linear_fused_plan(_C.NDCG2, 512, 512, 700) == _C.PLAN_GENERAL             # rankings: not in parts
+    assert lib.ltr_linear_fused_plan(_C.NDCG2, 512, 512, 700) == _C.PLAN_PARTS               # round 4: every part ranks the query itself
+    assert lib.ltr_linear_fused_plan(_C.NDCG1, 256, 1000, 700) == _C.PLAN_PARTS
+    assert lib.ltr_linear_fused_plan(_C.NDCG2, 512, 512, 220) == _C.PLAN_GENERAL             # narrow rows, as for the other kinds
     assert lib.ltr_linear_fused_plan(_C.HINGE, 48, 2000, 64) == _C.PLAN_PARTS                # beyond the symmetric pass
     assert lib.ltr_linear_fused_plan(_C.NDCG2, 256, 1000, 220) == _C.PLAN_GENERAL            # rankings: small batches only
     assert lib.ltr_linear_fused_plan(_C.NDCG2, 32, 1000, 220) == _C.PLAN_CLUSTER
+    # where the parts kernel is measured to lose it is not picked (round 4: cold parts / general sweeps)
+    assert lib.ltr_linear_fused_plan(_C.HINGE, 256, 300, 700) == _C.PLAN_GENERAL              # short lists, one workgroup per CU
+    assert lib.ltr_linear_fused_plan(_C.LOGISTIC, 512, 512, 448) == _C.PLAN_GENERAL           # 112 float4 per row: the heavy kinds lose
+    assert lib.ltr_linear_fused_plan(_C.ARP1, 768, 1000, 448) == _C.PLAN_GENERAL
+    assert lib.ltr_linear_fused_plan(_C.LOGISTIC, 256, 1000, 700) == _C.PLAN_PARTS
+    assert lib.ltr_linear_fused_plan(_C.HINGE, 160, 1000, 512) == _C.PLAN_PARTS               # the general kernel would leave CUs empty
+    old = lib.ltr_debug_parts_all(1)                                                          # tests: every shape it can take
+    assert lib.ltr_linear_fused_plan(_C.HINGE, 256, 300, 700) == _C.PLAN_PARTS
+    assert lib.ltr_debug_parts_all(old) == 1
     assert lib.ltr_linear_fused_plan(_C.HINGE, 8, 5000, 136) == _C.PLAN_NONE                 # list_len > 4096
     assert lib.ltr_linear_fused_plan(99, 8, 100, 136) == _C.PLAN_NONE
     # the cluster kernel's scratch rides behind the (F+1, B) partials

@@ -23,6 +23,20 @@ def _dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(autouse=True)
+def _parts_kernel_wherever_it_applies(request):
+    """The tests of the parts kernel's mechanics (exchange areas, tags, graph replay, the counting formulation, every
+    kind) run on shapes smaller or narrower than the ones where the kernel is measured to pay and the dispatcher
+    picks it (choose_parts_shape): for them ltr_debug_parts_all lets it take every shape it can.  The BASELINE
+    shapes (C4, C5 and their shards) are tested on the plan the dispatcher really picks."""
+    from pytorchltr_amd import _C
+    name = request.node.name
+    on = ("parts_kernel" in name or "exchange_area" in name) and "c5_full_size" not in name
+    old = _C.lib().ltr_debug_parts_all(1 if on else 0)
+    yield
+    _C.lib().ltr_debug_parts_all(old)
+
+
 def _run(kind, B, L, F, seed, want_plan, busy=False):
     from pytorchltr_amd import _C
     from pytorchltr_amd.fused import linear_loss_step
@@ -86,9 +100,12 @@ def test_c5_full_size_general_kernel_all_rows():
 
 
 @pytest.mark.parametrize("shape", [("hinge", 48, 2000, 64), ("dcg_hinge", 20, 4000, 32), ("logistic", 300, 512, 700),
-                                   ("arp1", 400, 600, 512), ("arp2", 600, 300, 448)])
+                                   ("arp1", 400, 600, 512), ("arp2", 600, 300, 448),
+                                   # round 4: the rank-dependent kinds (every part ranks the whole query itself)
+                                   ("ndcg2", 512, 512, 700), ("ndcg1", 512, 512, 700), ("ndcg2", 300, 300, 448),
+                                   ("ndcg1", 150, 1000, 512), ("ndcg2", 90, 768, 640), ("ndcg2", 300, 400, 700)])
 def test_parts_kernel_shapes_all_rows(shape):
-    """Long lists (beyond the symmetric pass) and wide rows, every rank-free kind, all rows."""
+    """Long lists (beyond the symmetric pass) and wide rows, every kind, all rows."""
     from pytorchltr_amd import _C
     kind, B, L, F = shape
     _run(kind, B, L, F, 4, _C.PLAN_PARTS)
