@@ -993,6 +993,34 @@ def n1_extras(args, kind, B, L, F, dev, batches, steps_timed):
         loss_fn(scorer(b0["X"]), b0["rel"], b0["n"]).mean().backward()
     extra["dropin_use_linear_scorer_plus_loss_module"] = measure(dropin_scorer_step)
 
+    # (b3) the whole training step of examples/01-basic-usage.py:66-75 as the user writes it -- model = use_linear_scorer(
+    # nn.Linear(F, 1)), loss_fn(model(xs), ys, n).mean().backward(), torch.optim.SGD step -- captured ONCE by
+    # pytorchltr_amd.GraphedStep and replayed per batch (the eager figures above vary 2x between
+    # boxes, the replayed step does not).  Timed with the copy of each batch into the static buffers left out
+    # (graph replay only: the batch is already on the device) and with it (step(xs, ys, n) as documented).
+    if not args.no_graph:
+        try:
+            from pytorchltr_amd.graphed import GraphedStep
+            gmodel = use_linear_scorer(torch.nn.Linear(F, 1).to(dev))
+            gopt = torch.optim.SGD(gmodel.parameters(), lr=1e-6)
+            gstep = GraphedStep(gmodel, gopt, lambda xs, ys, n_: loss_fn(gmodel(xs), ys, n_).mean(),
+                                example_batch=(b0["X"], b0["rel"], b0["n"]))
+            for _ in range(20):
+                gstep._graph.replay()
+            t_replay = median(time_region(lambda i: gstep._graph.replay(), reps, lambda: None, repeats=3)) / reps
+            for _ in range(5):
+                gstep(b0["X"], b0["rel"], b0["n"])
+            t_call = median(time_region(lambda i: gstep(batches[i % nbuf]["X"], batches[i % nbuf]["rel"], batches[i % nbuf]["n"]),
+                                        max(50, reps // 4), lambda: None, repeats=3)) / max(50, reps // 4)
+            extra["graphed_step_dropin_sgd"] = {
+                "what": "GraphedStep(use_linear_scorer(nn.Linear(F,1)), SGD, loss_fn(model(xs), ys, n).mean()): forward + backward + "
+                        "optimizer.step() replayed as one hipGraph",
+                "replay_us_per_step": t_replay * 1e6, "replay_queries_per_s": B / t_replay,
+                "call_with_batch_copy_us_per_step": t_call * 1e6, "call_with_batch_copy_queries_per_s": B / t_call,
+                "batch_copy_bytes": int(b0["X"].numel() * 4 + b0["rel"].numel() * b0["rel"].element_size() + b0["n"].numel() * 8)}
+        except Exception as exc:  # pragma: no cover - depends on the runtime's capture support
+            extra["graphed_step_dropin_sgd"] = {"error": repr(exc)[:200]}
+
     # (c) loss only (the literal "loss fwd+bwd" on precomputed scores), reference call signature
     sc = b0["scores"].clone().requires_grad_(True)
 

@@ -188,7 +188,8 @@ def test_fused_plan_for_the_baseline_shapes():
     assert lib.ltr_linear_fused_plan(_C.NDCG1, 256, 1000, 700) == _C.PLAN_PARTS
     assert lib.ltr_linear_fused_plan(_C.NDCG2, 512, 512, 220) == _C.PLAN_GENERAL             # narrow rows, as for the other kinds
     assert lib.ltr_linear_fused_plan(_C.HINGE, 48, 2000, 64) == _C.PLAN_PARTS                # beyond the symmetric pass
-    assert lib.ltr_linear_fused_plan(_C.NDCG2, 256, 1000, 220) == _C.PLAN_GENERAL            # rankings: small batches only
+    assert lib.ltr_linear_fused_plan(_C.NDCG2, 256, 1000, 220) == _C.PLAN_GENERAL            # rankings: only where CUs would stay empty
+    assert lib.ltr_linear_fused_plan(_C.NDCG1, 128, 1000, 136) == _C.PLAN_PARTS               # ... as here (round 4)
     assert lib.ltr_linear_fused_plan(_C.NDCG2, 32, 1000, 220) == _C.PLAN_CLUSTER
     # where the parts kernel is measured to lose it is not picked (round 4: cold parts / general sweeps)
     assert lib.ltr_linear_fused_plan(_C.HINGE, 256, 300, 700) == _C.PLAN_GENERAL              # short lists, one workgroup per CU
