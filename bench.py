@@ -383,6 +383,30 @@ def mlp_extra(kind, batches, no_graph):
            "useful_TFLOPs": docs * flops_per_doc / (us * 1e-6) / 1e12,
            "f32_mfma_peak_TFLOPs": 157.3,
            "frac_of_f32_mfma_peak": docs * flops_per_doc / (us * 1e-6) / 1e12 / 157.3}
+    # the launch-geometry ceiling of that step: the tile kernel's grid, fills, LDS image, barriers and
+    # MFMA streams with nothing else (the same query assignment; no labels, per-document layers 2-3, parking, pair pass, partial
+    # vectors, reduction launch) -- ltr_debug_mlp_probe_f32, cold over the same rotation
+    if F == 136 and L <= 128 and hasattr(lib, "ltr_debug_mlp_probe_f32"):
+        pout = torch.empty(4096, device=dev)
+
+        def probe(i):
+            b = batches[i % nbuf]
+            _C.check(lib.ltr_debug_mlp_probe_f32(b["X"].data_ptr(), *[p.data_ptr() for p in params], b["n"].data_ptr(),
+                                                 B, L, F, H1, H2, pout.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        for i in range(nbuf):
+            probe(i)
+        pus, _ = time_launches(probe, nbuf, rounds=2, replays=10)
+        # MFMAs the geometry issues: 80 forward + 88 backward per 32-row fill and wave, 4 waves; 2048 flop each
+        fills = sum(int(((b["n"].clamp(max=L) + 31) // 32).clamp(min=1).sum()) for b in batches) / float(nbuf)
+        mfma_flops = fills * 4 * 168 * 2048.0
+        out["launch_ceiling"] = {
+            "us": pus, "step_over_ceiling": us / pus,
+            "useful_frac_of_f32_mfma_peak_at_ceiling": docs * flops_per_doc / (pus * 1e-6) / 1e12 / 157.3,
+            "issued_mfma_TFLOPs_at_ceiling": mfma_flops / (pus * 1e-6) / 1e12,
+            "issued_over_useful_flops": mfma_flops / (docs * flops_per_doc),
+            "what": "mlp_tile_kernel<PROBE>: same grid (2 workgroups of 4 waves per CU), same 32-row fills requested / written to "
+                    "the LDS image / read back, same barriers, same 168 MFMAs (v_mfma_f32_16x16x4_f32) per fill and wave; same "
+                    "assignment of queries to workgroups; no labels, owner-wave layers 2-3, parking, pair pass, partial vectors or reduction launch"}
     loss_fn = {"hinge": L_.PairwiseHingeLoss, "dcg_hinge": L_.PairwiseDCGHingeLoss,
                "logistic": L_.PairwiseLogisticLoss, "arp1": L_.LambdaARPLoss1, "arp2": L_.LambdaARPLoss2,
                "ndcg1": L_.LambdaNDCGLoss1, "ndcg2": L_.LambdaNDCGLoss2}[kind]()

@@ -424,6 +424,15 @@ int ltr_mlp_pairwise_f32(int kind, float sigma, const float *X, const float *W1,
                          float *grads, float *loss_sum, void *workspace, size_t workspace_bytes,
                          void *stream);
 
+/* Measurement aid (bench.py `extra.mlp_scorer_fused.launch_ceiling`): the launch geometry of the fused MLP training
+ * step -- the tile kernel's grid and workgroups, the same 32-row fills requested, written to the LDS image and read
+ * back, the same barriers and MFMA streams (80 forward + 88 backward MFMAs per fill and wave), the same assignment of queries to
+ * workgroups -- with no labels, per-document layer-2/3 work, parking, pair pass or partial vectors: every wave stores one dword to
+ * out (2 * #CUs * 4 floats at most).  F = 136 and L <= 128 only (the named batch); the numbers mean nothing. */
+int ltr_debug_mlp_probe_f32(const float *X, const float *W1, const float *b1, const float *W2, const float *b2,
+                            const float *W3, const float *b3, const int64_t *n, int B, int L, int F, int H1, int H2,
+                            float *out, void *stream);
+
 /* The same network, forward only: scores_out (B,L) = model(X) for documents < n[b], 0 for the
  * padded ones -- the `model(xs)` of the guide's evaluation loop (docs/source/getting-started.rst:
  * 117-127) without the rocBLAS round trips.  Same shape limits as ltr_mlp_pairwise_f32; no

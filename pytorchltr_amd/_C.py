@@ -36,6 +36,7 @@ SIGNATURES = {
     "ltr_debug_set_exchange_tag": (_i, [_vp, ctypes.c_uint32]),
     "ltr_debug_stream_probe_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ltr_debug_mlp_layout": (None, [_i]),
+    "ltr_debug_mlp_probe_f32": (_i, [_vp] * 8 + [_i] * 5 + [_vp, _vp]),
     "ltr_pairwise_loss_f32": (_i, [_i, _f, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "ltr_pairwise_loss_f32_cfg": (_i, [_i, _f, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     "ltr_pairwise_loss_workspace_bytes": (_sz, [_i, _i, _i]),

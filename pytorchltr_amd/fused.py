@@ -187,8 +187,10 @@ class FusedLinearLoss(torch.nn.Module):
         if B <= 0 or _C.lib().ltr_pairwise_loss_workspace_bytes(self.kind, B, L) == 0:
             return False
         # the cluster kernel (features once, a query over several workgroups) beats the pieces
-        # wherever it applies: 32 x 1000 x 220 hinge 32 vs 46 us, logistic 43 vs 52
-        if _C.lib().ltr_linear_fused_plan(self.kind, B, L, self.in_features) == _C.PLAN_CLUSTER:
+        # wherever it applies: 32 x 1000 x 220 hinge 32 vs 46 us, logistic 43 vs 52 -- and so does the parts
+        # kernel (round 4, module forward + backward replayed, pieces vs fused: 64 x 512 x 700 LambdaNDCG2 91 vs 48 us,
+        # 100 x 1000 x 700 hinge 120 vs 78, LambdaNDCG1 149 vs 107, 80 x 700 x 512 LambdaNDCG2 88 vs 68)
+        if _C.lib().ltr_linear_fused_plan(self.kind, B, L, self.in_features) in (_C.PLAN_CLUSTER, _C.PLAN_PARTS):
             return False
         cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
         if 2 * B <= cus:

@@ -188,8 +188,12 @@ def test_fused_plan_for_the_baseline_shapes():
     assert lib.ltr_linear_fused_plan(_C.NDCG1, 256, 1000, 700) == _C.PLAN_PARTS
     assert lib.ltr_linear_fused_plan(_C.NDCG2, 512, 512, 220) == _C.PLAN_GENERAL             # narrow rows, as for the other kinds
     assert lib.ltr_linear_fused_plan(_C.HINGE, 48, 2000, 64) == _C.PLAN_PARTS                # beyond the symmetric pass
-    assert lib.ltr_linear_fused_plan(_C.NDCG2, 256, 1000, 220) == _C.PLAN_GENERAL            # rankings: only where CUs would stay empty
-    assert lib.ltr_linear_fused_plan(_C.NDCG1, 128, 1000, 136) == _C.PLAN_PARTS               # ... as here (round 4)
+    # round 4: the rank exchange lets the cluster kernel take the NDCG kinds like the other heavy kinds
+    assert lib.ltr_linear_fused_plan(_C.NDCG2, 256, 1000, 220) == _C.PLAN_CLUSTER            # C4's shape with LambdaNDCG2
+    assert lib.ltr_linear_fused_plan(_C.NDCG2, 384, 1000, 220) == _C.PLAN_GENERAL            # (measured: loses there)
+    assert lib.ltr_linear_fused_plan(_C.NDCG1, 384, 1000, 220) == _C.PLAN_CLUSTER
+    assert lib.ltr_linear_fused_plan(_C.NDCG1, 128, 1000, 136) == _C.PLAN_CLUSTER
+    assert lib.ltr_linear_fused_plan(_C.NDCG2, 128, 512, 700) == _C.PLAN_PARTS                # wide rows: the parts kernel
     assert lib.ltr_linear_fused_plan(_C.NDCG2, 32, 1000, 220) == _C.PLAN_CLUSTER
     # where the parts kernel is measured to lose it is not picked (round 4: cold parts / general sweeps)
     assert lib.ltr_linear_fused_plan(_C.HINGE, 256, 300, 700) == _C.PLAN_GENERAL              # short lists, one workgroup per CU

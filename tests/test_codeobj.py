@@ -38,7 +38,7 @@ BASELINE_KERNELS = [
     "pairwise_loss_kernel<0, 0, 8>",                # loss only, C2 shape (symmetric pass, 8 waves)
     "pairwise_loss_kernel<6, 0, 8>",
     "metric_kernel<1, 0>",                          # ndcg@10 (C3)
-    "mlp_tile_kernel<0, 9, 34, 128, false>",        # f-2: the guide's MLP + hinge at the C2 shape
+    "mlp_tile_kernel<0, 9, 34, 128, false, false>",  # f-2: the guide's MLP + hinge at the C2 shape
     "mlp_reduce4_kernel",
 ]
 
@@ -80,4 +80,4 @@ def test_no_fused_scorer_kernel_outside_the_known_exceptions_spills():
 def test_spilling_kernel_count_only_goes_down():
     recs = _records()
     spilling = [r for r in recs if r.get("vgpr_spill_count", 0) > 0]
-    assert len(spilling) <= 39, sorted((r.get("demangled", r["name"])[:70], r["vgpr_spill_count"]) for r in spilling)
+    assert len(spilling) <= 31, sorted((r.get("demangled", r["name"])[:70], r["vgpr_spill_count"]) for r in spilling)
