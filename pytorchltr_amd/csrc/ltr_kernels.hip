@@ -928,6 +928,16 @@ static int choose_loss_splits(int kind, int B, int L)
     // kernel -> split, LambdaNDCG1/2: 32 x 1000: 130/144 -> 51/53 us; 128 x 600: 65/71 -> 46/48;
     // C4 256 x 1000: 132/145 -> 82/90; 384 x 1000: 132/146 -> 114/123; 300 x 400: 41/43 -> 44/46)
     const bool ndcg = (kind == LTR_NDCG1 || kind == LTR_NDCG2);
+    // Round 4 audit of the shorter lists (plain -> split, us; hinge / logistic / LambdaNDCG2): 256 x 300 7.9 / 13.5 / 28.1 ->
+    // 11.7 / 14.0 / 31.7 (!), 128 x 300 7.9 / 13.3 / 28.1 -> 9.5 / 10.9 / 28.6, 256 x 400 11.7 / 22.7 / 36.9 -> 12.9 / 16.7 / 35.8,
+    // 128 x 400 11.6 / 22.6 / 36.8 -> 9.9 / 12.5 / 29.9, 384 x 512 15.5 / 32.2 -> 17.5 / 27.2: the hinge kinds' pass is too
+    // short to be worth a second launch below 400 documents or beyond half a chip of 400-document queries
+    {
+        const bool hinge = (kind == LTR_HINGE || kind == LTR_DCG_HINGE);
+        if (L < 400 && (hinge || ndcg || 2 * B > cus)) return 1;
+        if (hinge && L < 512 && 2 * B > cus) return 1;
+        if (hinge && L < 640 && B > cus) return 1;
+    }
     if (ndcg && B > cus && L <= 512) return 1;
     if (2 * B > 3 * cus && !(!ndcg && B <= 2 * cus && L > 640)) return 1;
     // up to 8 parts per query; 16 on the smallest batches (64 x 1000: hinge 22.4 -> 16.5 us, logistic

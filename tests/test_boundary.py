@@ -201,6 +201,8 @@ def test_fused_plan_for_the_baseline_shapes():
     assert lib.ltr_linear_fused_plan(_C.ARP1, 768, 1000, 448) == _C.PLAN_GENERAL
     assert lib.ltr_linear_fused_plan(_C.LOGISTIC, 256, 1000, 700) == _C.PLAN_PARTS
     assert lib.ltr_linear_fused_plan(_C.HINGE, 160, 1000, 512) == _C.PLAN_PARTS               # the general kernel would leave CUs empty
+    assert lib.ltr_linear_fused_plan(_C.HINGE, 1024, 256, 700) == _C.PLAN_PARTS               # short lists, wide rows, large batch
+    assert lib.ltr_linear_fused_plan(_C.HINGE, 512, 128, 700) == _C.PLAN_GENERAL
     old = lib.ltr_debug_parts_all(1)                                                          # tests: every shape it can take
     assert lib.ltr_linear_fused_plan(_C.HINGE, 256, 300, 700) == _C.PLAN_PARTS
     assert lib.ltr_debug_parts_all(old) == 1

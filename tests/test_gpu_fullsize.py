@@ -111,7 +111,9 @@ def test_c5_full_size_general_kernel_all_rows():
                                    # round 4: the rank-dependent kinds (every part ranks the whole query itself)
                                    ("ndcg2", 512, 512, 700), ("ndcg1", 512, 512, 700), ("ndcg2", 300, 300, 448),
                                    ("ndcg1", 150, 1000, 512), ("ndcg2", 90, 768, 640), ("ndcg2", 300, 400, 700),
-                                   ("ndcg2", 128, 1000, 136), ("ndcg1", 100, 700, 220), ("ndcg2", 100, 400, 64)])
+                                   ("ndcg2", 128, 1000, 136), ("ndcg1", 100, 700, 220), ("ndcg2", 100, 400, 64),
+                                   # short lists on wide rows (Yahoo-shaped: the general kernel reads the features twice)
+                                   ("hinge", 600, 128, 700), ("logistic", 520, 256, 640), ("arp1", 300, 100, 512)])
 def test_parts_kernel_shapes_all_rows(shape):
     """Long lists (beyond the symmetric pass) and wide rows, every kind, all rows."""
     from pytorchltr_amd import _C
