@@ -97,6 +97,19 @@ def test_fused_step_c2_c3_full_lists_full_size(kind):
     _check(kind, 1024, 128, 136, 0, full=True)
 
 
+@pytest.mark.parametrize("kind", ["hinge", "dcg_hinge", "logistic", "arp1", "arp2"])
+@pytest.mark.parametrize("shape", [(300, 256, 136), (260, 200, 136), (150, 162, 220), (90, 256, 100), (64, 129, 220)])
+def test_fused_step_1024_thread_register_tile(kind, shape):
+    """Round 4: lists of 129 .. 256 documents at MSLR / Istella row widths on the 1024-thread register tile (nine sweeps; features read once instead of the general kernel's two passes), every rank-free kind, ragged and
+    full lists, with an upstream gradient."""
+    from pytorchltr_amd import _C
+    B, L, F = shape
+    assert _C.lib().ltr_linear_fused_plan(O.KINDS[kind], B, L, F) == _C.PLAN_REGISTER_TILE
+    _check(kind, B, L, F, 21)
+    _check(kind, min(B, 40), L, F, 22, full=True)
+    _check(kind, min(B, 40), L, F, 23, grad_out=torch.linspace(-0.5, 1.5, min(B, 40)))
+
+
 @pytest.mark.parametrize("shape", [(6, 1000, 220, "dcg_hinge"), (6, 512, 700, "hinge"),
                                    (4, 300, 64, "ndcg1"), (3, 2000, 16, "arp2")])
 def test_fused_step_large_tiles(shape):
