@@ -86,6 +86,15 @@ def test_c4_full_size_cluster_kernel_all_rows():
     _run("dcg_hinge", 256, 1000, 220, 0, _C.PLAN_CLUSTER, busy=True)
 
 
+def test_c4_shape_lambda_ndcg_on_the_cluster_kernel_with_the_rank_exchange():
+    """Round 4: C4's shape with the LambdaNDCG losses -- the members of a cluster rank their own rows and exchange the
+    ranks and their terms of maxDCG behind a FOURTH counter (one more in-launch wait): every row against the oracle,
+    twice bit-identical, and three more times under a busy second stream."""
+    from pytorchltr_amd import _C
+    _run("ndcg2", 256, 1000, 220, 2, _C.PLAN_CLUSTER, busy=True)
+    _run("ndcg1", 200, 700, 136, 3, _C.PLAN_CLUSTER, busy=True)
+
+
 def test_c4_shard_of_8_gpus_cluster_kernel():
     from pytorchltr_amd import _C
     _run("dcg_hinge", 32, 1000, 220, 1, _C.PLAN_CLUSTER)
