@@ -69,6 +69,69 @@ def test_fused_step_random_shapes(shape):
     _check(kind, B, L, F, seed=B + L + F)
 
 
+def _round4_shapes(count, seed):
+    """Seeded shapes from the regimes whose dispatch changed in round 4 (scripts/dev/fuzz_dispatch.py is the long-running
+    version: it found a workspace sized for two kinds only)."""
+    import random
+    rnd = random.Random(seed)
+    out = []
+    for _ in range(count):
+        regime = rnd.choice(["wide", "wide_short", "rt1024", "ndcg_cluster", "ndcg_parts"])
+        kind = rnd.choice(list(KINDS))
+        if regime == "wide":
+            B, L, F = rnd.choice([65, 130, 257, 300]), rnd.choice([300, 400, 512, 768, 1000]), rnd.choice([448, 512, 576, 640, 700])
+        elif regime == "wide_short":
+            B, L, F = rnd.choice([512, 520]), rnd.choice([100, 128, 200, 256]), rnd.choice([640, 700])
+        elif regime == "rt1024":
+            kind = rnd.choice(["hinge", "dcg_hinge", "logistic", "arp1", "arp2"])
+            B, L, F = rnd.choice([3, 64, 257]), rnd.choice([129, 150, 181, 200, 255, 256]), rnd.choice([100, 120, 136, 160, 220])
+        elif regime == "ndcg_cluster":
+            kind = rnd.choice(["ndcg1", "ndcg2"])
+            B, L, F = rnd.choice([5, 33, 100, 272, 380]), rnd.choice([257, 300, 512, 700, 1000, 1024]), rnd.choice([16, 64, 136, 220])
+        else:
+            kind = rnd.choice(["ndcg1", "ndcg2"])
+            B, L, F = rnd.choice([70, 128, 190]), rnd.choice([400, 512, 600, 768, 1000]), rnd.choice([448, 512, 640, 700])
+        if B * L * F > 70_000_000:
+            B = max(1, 70_000_000 // (L * F))
+        out.append((B, L, F, kind, rnd.randrange(4)))
+    return out
+
+
+@pytest.mark.parametrize("shape", _round4_shapes(40, 20260930), ids=lambda s: "%dx%dx%d-%s-p%d" % s)
+def test_fused_step_round4_dispatch_regimes(shape):
+    """Wide rows on the parts kernel (long and short lists, every kind), the 1024-thread register tile, the NDCG kinds on
+    the cluster kernel: whatever plan the dispatcher picks, losses and gradients against the fp64 oracle, twice
+    bit-identical, ragged / full / mixed / short list-length patterns."""
+    from pytorchltr_amd import _C
+    from pytorchltr_amd.fused import linear_loss_step
+    B, L, F, kind, pat = shape
+    dev = _dev()
+    s, y, n, X, W, b = synth(B, L, B + L + F + pat, F=F)
+    g = torch.Generator().manual_seed(B * 7 + L)
+    if pat == 1:
+        n = torch.full_like(n, L)
+    elif pat == 2:
+        n = torch.where(torch.rand(B, generator=g) < 0.5, torch.full_like(n, L), n)
+    elif pat == 3:
+        n = torch.clamp(n, max=max(1, L // 3))
+    n[0] = 0
+    outs = []
+    for rep in range(2):
+        loss, dW, db = linear_loss_step(X.to(dev), W.to(dev), b.to(dev), y.to(dev), n.to(dev), loss=kind)
+        outs.append((loss.cpu().numpy(), dW.cpu().numpy(), db.cpu().numpy()))
+    _C.device_status()
+    assert all(np.array_equal(a, c) for a, c in zip(outs[0], outs[1]))
+    want_l, _, want_dW, want_db = O.linear_pairwise(kind, X.numpy(), W.numpy(), float(b[0]), y.numpy(), n.numpy(), np.full(B, 1.0 / B))
+    loss, dW, db = outs[0]
+    ok = np.isclose(loss, want_l, rtol=5e-4 if L > 256 else 2e-5, atol=1e-5)
+    if kind in ("ndcg1", "ndcg2"):      # (fp32 scores can swap two nearly tied ranks against the fp64 oracle: a row or two, within 5e-3)
+        assert ok.mean() >= 0.97 and np.allclose(loss, want_l, rtol=5e-3, atol=1e-5)
+    else:
+        assert ok.all()
+    tol = 4e-4 * max(1.0, float(np.max(np.abs(want_dW))))
+    assert np.max(np.abs(dW - want_dW)) < tol and abs(float(db[0]) - want_db) < tol
+
+
 @pytest.mark.parametrize("kind", KINDS)
 def test_fused_step_small_shapes(kind):
     _check(kind, 8, 16, 5, 1234)                 # scalar path (F % 4 != 0), Example3-like F
