@@ -6,7 +6,7 @@ from tests.conftest import synth
 from pytorchltr_amd import _C
 from pytorchltr_amd.fused import linear_loss_step
 dev = torch.device("cuda:0")
-for kind, B, L, F in [("ndcg2", 200, 256, 136), ("ndcg1", 200, 200, 136), ("ndcg2", 100, 162, 220), ("ndcg1", 64, 256, 100)]:
+for kind, B, L, F in [("ndcg2", 200, 256, 136), ("ndcg1", 200, 200, 136), ("ndcg2", 100, 162, 220), ("ndcg1", 64, 256, 100), ("ndcg2", 50, 285, 136)]:
     s, y, n, X, W, b = synth(B, L, 4, F=F)
     n[:4] = torch.tensor([0, 1, L, L - 1])
     print(kind, B, L, F, "plan", _C.lib().ltr_linear_fused_plan(getattr(_C, kind.upper()), B, L, F))

@@ -31,8 +31,8 @@ while time.time() < t_end:
     else:
         kind = rnd.choice(["ndcg1", "ndcg2"])
         B, L, F = rnd.choice([70, 128, 190, 256, 400]), rnd.choice([400, 512, 600, 768, 1000]), rnd.choice([448, 512, 640, 700, 764])
-    if B * L * F > 60_000_000:
-        B = max(1, 60_000_000 // (L * F))
+    if B * L * F > 110_000_000:
+        B = max(1, 110_000_000 // (L * F))
     g = torch.Generator().manual_seed(rnd.randrange(1 << 30))
     y = torch.randint(0, 5, (B, L), generator=g)
     X = torch.randn(B, L, F, generator=g)

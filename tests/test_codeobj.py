@@ -65,10 +65,6 @@ def test_no_fused_scorer_kernel_outside_the_known_exceptions_spills():
     known = ("linear_parts_kernel<0, 40, 1, 2, 1>", "linear_parts_kernel<0, 20, 2, 2, 1>", "linear_parts_kernel<0, 14, 3, 2, 1>",
              "linear_parts_kernel<1, 40, 1, 2, 1>", "linear_parts_kernel<1, 20, 2, 2, 1>", "linear_parts_kernel<1, 14, 3, 2, 1>",
              "linear_regtile_kernel<", "linear_regtile2_kernel<5, 12,", "linear_regtile2_kernel<6, 12,",
-             # the 1024-thread tile with run-time loop bounds (feature counts other than 136) at nine sweeps: 2 VGPRs under
-             # the 64 that two workgroups per CU allow
-             "linear_regtile2_kernel<0, 9, 0, 1024>", "linear_regtile2_kernel<1, 9, 0, 1024>", "linear_regtile2_kernel<2, 9, 0, 1024>",
-             "linear_regtile2_kernel<3, 9, 0, 1024>", "linear_regtile2_kernel<4, 9, 0, 1024>",
              "linear_cluster_kernel<5,", "linear_cluster_kernel<6,", "linear_cluster_kernel<2, 512, 12>",
              "linear_cluster_kernel<4, 512, 12>")
     bad = []
@@ -84,4 +80,4 @@ def test_no_fused_scorer_kernel_outside_the_known_exceptions_spills():
 def test_spilling_kernel_count_only_goes_down():
     recs = _records()
     spilling = [r for r in recs if r.get("vgpr_spill_count", 0) > 0]
-    assert len(spilling) <= 36, sorted((r.get("demangled", r["name"])[:70], r["vgpr_spill_count"]) for r in spilling)
+    assert len(spilling) <= 31, sorted((r.get("demangled", r["name"])[:70], r["vgpr_spill_count"]) for r in spilling)
