@@ -174,7 +174,8 @@ ndcg_prepare_kernel(LossParams p, float2 *prep)
     const int T = blockDim.x;
     const int L4 = (L + 63) & ~63;
     const int nb = clamp_n(p.n[b], L);
-    const QueryLds q = carve_query_lds<KIND>(smem, L4, T >> 6);
+    // (no gradient slices here: beyond 1024 documents the region behind the rank arrays is sized for the sort alone)
+    const QueryLds q = carve_query_lds<KIND>(smem, L4, L4 > kSymMaxLen ? 4 : (T >> 6));
     const size_t row = (size_t)b * L;
     stage_rows(q.sy, p.scores + row, p.rel, p.rel_dtype, row, L, nb, tid, T);
     for (int m = tid; m < 2 * L4; m += T) q.rank_s[m] = 0;
@@ -854,11 +855,12 @@ LaunchShape choose_shape(int B, int L)
 LaunchShape choose_loss_shape(int B, int L)
 {
 #ifndef LTR_NO_SYM
-    if (L <= kSymMaxLen) {
+    if (L <= kLossSymMaxLen) {
         LaunchShape s;
         s.dpt = 0;
         s.owners = 64;
-        s.msplit = (L <= 128) ? 4 : (L <= 256 ? 8 : 16);   // waves per query
+        // waves per query (beyond 1024 documents: eight -- sixteen gradient slices of 2048 floats do not fit the LDS)
+        s.msplit = (L <= 128) ? 4 : (L <= 256 ? 8 : (L <= kSymMaxLen ? 16 : 8));
         (void)B;
         return s;
     }
@@ -919,7 +921,7 @@ int launch_loss(int kind, const LossParams &p, const LaunchShape &s, hipStream_t
 constexpr int kSplitWaves = LTR_SPLIT_WAVES;   // waves per part: small workgroups, many per CU
 static int choose_loss_splits(int kind, int B, int L)
 {
-    if (L <= 256 || L > kSymMaxLen) return 1;
+    if (L <= 256 || L > kLossSymMaxLen) return 1;
     const int cus = device_cu_count();
     // measured (hinge / logistic, us, plain kernel with the list-length order -> split launch):
     // 384 x 1000: 35/66 either way; 512 x 1000: 58/135 -> 43/90; 768 x 1000: 71/163 -> 69/149;
@@ -962,7 +964,7 @@ static int launch_loss_split(const LossParams &p, int nsplit, float *ws, hipStre
         // (behind the raw sums and gradient slices; 8-byte aligned: an even number of floats precedes it)
         prep = reinterpret_cast<float2 *>(ws + (((size_t)p.B * nsplit * ((size_t)p.L + 1) + 1) & ~(size_t)1));
         constexpr int PK = (KIND == LTR_NDCG1 || KIND == LTR_NDCG2) ? KIND : LTR_NDCG1;
-        const size_t plds = loss_lds_bytes(PK, (p.L + 63) & ~63, 16);
+        const size_t plds = loss_lds_bytes(PK, (p.L + 63) & ~63, ((p.L + 63) & ~63) > kSymMaxLen ? 4 : 16);
         LTR_ENSURE_LDS((ndcg_prepare_kernel<PK>), plds);
         hipLaunchKernelGGL((ndcg_prepare_kernel<PK>), dim3((unsigned)p.B), dim3(1024), plds, stream, p, prep);
     }
@@ -1069,7 +1071,7 @@ int ltr_pairwise_loss_f32_cfg(int kind, float sigma, const float *scores, const 
     if (B == 0) return LTR_OK;
     if (!scores || !rel || !n || !loss) return LTR_ERR_NULL;
     if (owners <= 0 || owners % 64 != 0 || msplit <= 0 || owners * msplit > 1024 ||
-        (dpt != 0 && dpt != 1 && dpt != 2 && dpt != 4) || (dpt == 0 && L > kSymMaxLen))
+        (dpt != 0 && dpt != 1 && dpt != 2 && dpt != 4) || (dpt == 0 && L > kLossSymMaxLen))
         return LTR_ERR_CONFIG;
     {
         const LaunchShape chk{owners, dpt, msplit};
@@ -1090,6 +1092,7 @@ int ltr_pairwise_loss_f32(int kind, float sigma, const float *scores, const void
     LTR_CLEAR_STALE_ERROR();
     if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
     LaunchShape s = choose_loss_shape(B, L);
+    if (s.dpt == 0 && loss_lds_bytes_cfg(kind, L, s) > kLdsBudget) s = choose_shape(B, L);
     while (s.dpt != 0 && s.msplit > 1 && loss_lds_bytes(kind, L, s.msplit) > kLdsBudget) s.msplit /= 2;
     return ltr_pairwise_loss_f32_cfg(kind, sigma, scores, rel, rel_dtype, n, B, L, loss, dscores,
                                      s.owners, s.dpt, s.msplit, stream);

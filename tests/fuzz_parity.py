@@ -22,7 +22,7 @@ while time.time() < t_end:
     mode = rnd.choice(["loss", "loss_ws", "fused"])
     kind = rnd.choice(KINDS)
     B = rnd.choice([1, 2, 7, 33, 64, 100, 257, 300, 600, 1024, 1100, 2048])
-    L = rnd.choice([1, 2, 5, 17, 64, 65, 128, 129, 200, 256, 257, 300, 512, 700, 1000])
+    L = rnd.choice([1, 2, 5, 17, 64, 65, 128, 129, 200, 256, 257, 300, 512, 700, 1000, 1025, 1100, 1251, 1500, 2048, 2049])
     if B * L > 700 * 1000: continue
     F = rnd.choice([4, 8, 12, 64, 136, 220])
     g = torch.Generator().manual_seed(rnd.randrange(1 << 30))

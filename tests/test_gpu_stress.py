@@ -179,6 +179,35 @@ def test_split_query_launch_matches_single_workgroup(kind, shape):
     _check_grad(b_g[rows].cpu().numpy(), want_g, kind)
 
 
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("shape", [(3, 1025), (40, 1100), (300, 1300), (20, 2048), (600, 1251)])
+def test_loss_kernels_between_1024_and_2048_documents(kind, shape):
+    """Round 4: the symmetric pass (eight waves) and the split launch reach 2048 documents in the loss-only kernels --
+    an untruncated MSLR-WEB30K batch has lists of up to 1251; above 1024 the both-ends pass was 4-7x slower.  Plain and
+    workspace entry points against each other and against the oracle on a few rows, empty / one-document / full lists,
+    padded slots exactly zero."""
+    from pytorchltr_amd import _C
+    from pytorchltr_amd._autograd import pairwise_loss_and_grad
+    dev = torch.device("cuda")
+    B, L = shape
+    scores, y, n = synth(B, L, 5 + L)
+    n[:3] = torch.tensor([L, 1, 0])[:min(3, B)]
+    kid = getattr(_C, kind.upper())
+    a_l, a_g = pairwise_loss_and_grad(scores.to(dev), y.to(dev), n.to(dev), kid)
+    b_l, b_g = pairwise_loss_and_grad(scores.to(dev), y.to(dev), n.to(dev), kid, cfg="split")
+    assert torch.allclose(a_l, b_l, rtol=5e-5, atol=1e-5)
+    scale = a_g.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+    assert bool(((a_g - b_g).abs() <= 5e-5 * scale + 1e-6).all())
+    pad = torch.arange(L)[None, :] >= n.clamp(max=L)[:, None]
+    assert not a_g.cpu()[pad].any() and not b_g.cpu()[pad].any()
+    rows = slice(0, min(B, 5))
+    want_l, want_g = O.pairwise_loss(kind, scores[rows].numpy(), y[rows].numpy(), n[rows].numpy())
+    for got_l, got_g in ((a_l, a_g), (b_l, b_g)):
+        _check_loss(got_l[rows].cpu().numpy(), want_l, L, kind)
+        _check_grad(got_g[rows].cpu().numpy(), want_g, kind)
+    _C.device_status()
+
+
 def test_split_query_launch_through_the_module_and_forward_only():
     """The loss modules take the split launch by themselves for long lists on small batches:
     forward-only (no gradient buffer) and forward+backward agree with the direct kernel."""
