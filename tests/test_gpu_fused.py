@@ -160,6 +160,20 @@ def test_fused_step_c2_c3_full_lists_full_size(kind):
     _check(kind, 1024, 128, 136, 0, full=True)
 
 
+@pytest.mark.parametrize("kind", ["hinge", "dcg_hinge", "logistic", "arp1", "arp2"])
+@pytest.mark.parametrize("shape", [(150, 200, 220), (64, 216, 220), (70, 182, 220)])
+def test_fused_step_24_sweep_register_tile(kind, shape):
+    """Round 4: lists of 172 .. 216 documents at Istella's row width (Istella-S reaches 182) on a 24-sweep tile, the
+    rank-free kinds (the NDCG kinds would spill there and keep the general kernel)."""
+    from pytorchltr_amd import _C
+    B, L, F = shape
+    assert _C.lib().ltr_linear_fused_plan(O.KINDS[kind], B, L, F) == _C.PLAN_REGISTER_TILE
+    assert _C.lib().ltr_linear_fused_plan(_C.NDCG2, B, L, F) != _C.PLAN_REGISTER_TILE
+    _check(kind, B, L, F, 31)
+    _check(kind, min(B, 40), L, F, 32, full=True)
+    _check(kind, min(B, 40), L, F, 33, grad_out=torch.linspace(-0.5, 1.5, min(B, 40)))
+
+
 @pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("shape", [(300, 256, 136), (260, 200, 136), (150, 162, 220), (90, 256, 100), (64, 129, 220)])
 def test_fused_step_19_sweep_register_tile(kind, shape):
