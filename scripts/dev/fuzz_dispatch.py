@@ -23,8 +23,7 @@ while time.time() < t_end:
     elif regime == "wide_short":
         B, L, F = rnd.choice([512, 600, 1024]), rnd.choice([100, 128, 200, 256]), rnd.choice([640, 700, 764])
     elif regime == "rt1024":
-        kind = rnd.choice(["hinge", "dcg_hinge", "logistic", "arp1", "arp2"])
-        B, L, F = rnd.choice([3, 64, 257, 600]), rnd.choice([129, 150, 181, 200, 255, 256]), rnd.choice([100, 120, 136, 160, 220])
+        B, L, F = rnd.choice([3, 64, 257, 600]), rnd.choice([129, 150, 172, 181, 200, 216, 217, 255, 256]), rnd.choice([100, 120, 136, 160, 220, 300])
     elif regime == "ndcg_cluster":
         kind = rnd.choice(["ndcg1", "ndcg2"])
         B, L, F = rnd.choice([5, 33, 64, 100, 200, 256, 380]), rnd.choice([257, 300, 512, 700, 1000, 1024]), rnd.choice([16, 64, 136, 220, 384])
