@@ -1102,6 +1102,23 @@ def n1_extras(args, kind, B, L, F, dev, batches, steps_timed):
             cfgs[name] = {"error": repr(exc)}
     extra["configs"] = cfgs
 
+    # ---- shapes OFF the BASELINE grid whose plan changed in round 4 (same cold method; kernel us only): lists of 136..256
+    # documents at MSLR / Istella widths (19- / 24-sweep register tiles), Yahoo-shaped short lists with 700 features (parts
+    # kernel), the NDCG kinds on long lists at small batches (cluster / parts kernel with the rank exchange) ----
+    off = {}
+    for name, (b_, l_, f_, k_) in (("mslr_len256_hinge", (1024, 256, 136, "hinge")), ("mslr_len256_ndcg2", (1024, 256, 136, "ndcg2")),
+                                   ("istella_len200_hinge", (1024, 200, 220, "hinge")), ("yahoo_len128_hinge", (2048, 128, 700, "hinge")),
+                                   ("c4_shape_ndcg2", (256, 1000, 220, "ndcg2")), ("c4_shard8_ndcg2", (32, 1000, 220, "ndcg2"))):
+        try:
+            res, fs_, bt_ = measure_config(name, b_, l_, f_, k_, dev, 5000)
+            off[name] = {"shape": [b_, l_, f_], "loss": k_, "plan": res["plan"], "kernel_us": res["kernel_us"],
+                         "step_us": res["step_us"], "frac_moved": res["frac_moved"]}
+            del fs_, bt_
+            torch.cuda.empty_cache()
+        except Exception as exc:  # pragma: no cover
+            off[name] = {"error": repr(exc)}
+    extra["off_grid"] = off
+
     mlp = mlp_extra(kind, batches, args.no_graph)
     if mlp is not None:
         extra["mlp_scorer_fused"] = mlp
