@@ -69,6 +69,24 @@ def test_fused_step_random_shapes(shape):
     _check(kind, B, L, F, seed=B + L + F)
 
 
+def _check_ndcg_tolerant(kind, B, L, F):
+    """Two nearly tied fp32 scores of a 200-document list can rank the other way round than the fp64 oracle's: a row or
+    two move by ~1e-3 (the general kernel shows the same rows); everything else to the usual tolerances."""
+    from pytorchltr_amd.fused import linear_loss_step
+    dev = _dev()
+    for seed, full in ((21, False), (22, True)):
+        s_, y, n, X, W, b = synth(B, L, seed, F=F)
+        if full:
+            n = torch.full_like(n, L)
+        loss, dW, db = linear_loss_step(X.to(dev), W.to(dev), b.to(dev), y.to(dev), n.to(dev), loss=kind)
+        want_l, _, want_dW, want_db = O.linear_pairwise(kind, X.numpy(), W.numpy(), float(b[0]), y.numpy(), n.numpy(), np.full(B, 1.0 / B))
+        got = loss.cpu().numpy()
+        ok = np.isclose(got, want_l, rtol=2e-5, atol=1e-5)
+        assert ok.mean() >= 0.97 and np.allclose(got, want_l, rtol=5e-3, atol=1e-5)
+        tol = 2e-4 * max(1.0, float(np.max(np.abs(want_dW))))
+        assert np.max(np.abs(dW.cpu().numpy() - want_dW)) < tol and abs(float(db.cpu()[0]) - want_db) < tol
+
+
 def _round4_shapes(count, seed):
     """Seeded shapes from the regimes whose dispatch changed in round 4 (scripts/dev/fuzz_dispatch.py is the long-running
     version: it found a workspace sized for two kinds only)."""
@@ -160,15 +178,17 @@ def test_fused_step_c2_c3_full_lists_full_size(kind):
     _check(kind, 1024, 128, 136, 0, full=True)
 
 
-@pytest.mark.parametrize("kind", ["hinge", "dcg_hinge", "logistic", "arp1", "arp2"])
+@pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("shape", [(150, 200, 220), (64, 216, 220), (70, 182, 220)])
 def test_fused_step_24_sweep_register_tile(kind, shape):
-    """Round 4: lists of 172 .. 216 documents at Istella's row width (Istella-S reaches 182) on a 24-sweep tile, the
-    rank-free kinds (the NDCG kinds would spill there and keep the general kernel)."""
+    """Round 4: lists of 172 .. 216 documents at Istella's row width (Istella-S reaches 182) on a 24-sweep tile, every
+    kind."""
     from pytorchltr_amd import _C
     B, L, F = shape
     assert _C.lib().ltr_linear_fused_plan(O.KINDS[kind], B, L, F) == _C.PLAN_REGISTER_TILE
-    assert _C.lib().ltr_linear_fused_plan(_C.NDCG2, B, L, F) != _C.PLAN_REGISTER_TILE
+    if kind in ("ndcg1", "ndcg2"):
+        _check_ndcg_tolerant(kind, B, L, F)
+        return
     _check(kind, B, L, F, 31)
     _check(kind, min(B, 40), L, F, 32, full=True)
     _check(kind, min(B, 40), L, F, 33, grad_out=torch.linspace(-0.5, 1.5, min(B, 40)))
@@ -184,21 +204,7 @@ def test_fused_step_19_sweep_register_tile(kind, shape):
     B, L, F = shape
     assert _C.lib().ltr_linear_fused_plan(O.KINDS[kind], B, L, F) == _C.PLAN_REGISTER_TILE
     if kind in ("ndcg1", "ndcg2"):
-        # (two nearly tied fp32 scores of a 200-document list can rank the other way round than the fp64 oracle's: a
-        # row or two move by ~1e-3 -- the general kernel shows the same rows)
-        from pytorchltr_amd.fused import linear_loss_step
-        dev = _dev()
-        for seed, full in ((21, False), (22, True)):
-            s_, y, n, X, W, b = synth(B, L, seed, F=F)
-            if full:
-                n = torch.full_like(n, L)
-            loss, dW, db = linear_loss_step(X.to(dev), W.to(dev), b.to(dev), y.to(dev), n.to(dev), loss=kind)
-            want_l, _, want_dW, want_db = O.linear_pairwise(kind, X.numpy(), W.numpy(), float(b[0]), y.numpy(), n.numpy(), np.full(B, 1.0 / B))
-            got = loss.cpu().numpy()
-            ok = np.isclose(got, want_l, rtol=2e-5, atol=1e-5)
-            assert ok.mean() >= 0.97 and np.allclose(got, want_l, rtol=5e-3, atol=1e-5)
-            tol = 2e-4 * max(1.0, float(np.max(np.abs(want_dW))))
-            assert np.max(np.abs(dW.cpu().numpy() - want_dW)) < tol and abs(float(db.cpu()[0]) - want_db) < tol
+        _check_ndcg_tolerant(kind, B, L, F)
         return
     _check(kind, B, L, F, 21)
     _check(kind, min(B, 40), L, F, 22, full=True)
