@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Round-4 fuzz of the fused Linear scorer + loss step over the regimes whose dispatch changed (wide rows on the parts kernel
-incl. short lists and the NDCG kinds, the 1024-thread register tile, the NDCG kinds on the cluster kernel): random
+incl. short lists and the NDCG kinds, the 19- / 24-sweep register tiles, the NDCG kinds on the cluster kernel): random
 (kind, B, L, F, list-length pattern) against the fp64 C oracle; the plan the dispatcher picked is reported.
 Test infrastructure (uses oracle/), not collected by pytest:   python scripts/dev/fuzz_dispatch.py SEED SECONDS"""
 import sys, time, random, os

@@ -117,7 +117,7 @@ def _round4_shapes(count, seed):
 
 @pytest.mark.parametrize("shape", _round4_shapes(40, 20260930), ids=lambda s: "%dx%dx%d-%s-p%d" % s)
 def test_fused_step_round4_dispatch_regimes(shape):
-    """Wide rows on the parts kernel (long and short lists, every kind), the 1024-thread register tile, the NDCG kinds on
+    """Wide rows on the parts kernel (long and short lists, every kind), the 19- / 24-sweep register tiles, the NDCG kinds on
     the cluster kernel: whatever plan the dispatcher picks, losses and gradients against the fp64 oracle, twice
     bit-identical, ragged / full / mixed / short list-length patterns."""
     from pytorchltr_amd import _C
