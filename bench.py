@@ -53,9 +53,12 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 achievable
 CU_COUNT = 256
 CLOCK_HZ = 2.4e9            # max shader clock (MI355X_MICROARCH.md)
-VALU_ISSUE_PER_CYCLE = 256  # wave-instructions per cycle the chip retires at 4 cycles per wave64
-                            # VALU instruction and SIMD (measured: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU
-                            # = 1.00 quad-cycle, profiles/r01_c2_sq.txt): 1024 SIMDs / 4
+VALU_ISSUE_PER_CYCLE = 512  # wave-instructions per cycle: 1024 SIMDs x one wave64 instruction per 2 cycles
+                            # (MI355X_MICROARCH.md, SIMD-32).  Measured (profiles/r05_valu_issue.txt): a SIMD with
+                            # >= 2 waves issues v_add_f32 every 2.26 cycles, v_fma_f32 2.64, DPP moves 4.4, v_pk_fma_f32
+                            # 5.1; ONE wave alone issues every 4.9-5.9 cycles.  Rounds 1-4 used 256 (4 cycles, inferred
+                            # from SQ_ACTIVE_INST_VALU counting quad-cycles): every valu_issue_frac of those rounds
+                            # is twice the figure on this basis.
 L3_BYTES = 256 * 2 ** 20
 
 WORKLOADS = {
@@ -954,7 +957,7 @@ def loss_kernel_extra(workload, kind, B, L, dev, batches):
             "achieved_GBs": loss_bytes / (l_us * 1e-6) / 1e9,
             "frac_of_hbm_peak": loss_bytes / (l_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
             "valu_issue_frac": valu_frac(pmc.get("valu_insts_per_launch"), l_us),
-            "valu_basis": "SQ_INSTS_VALU per launch (profiles/pmc_%s.json) / (256 wave-instructions per "
+            "valu_basis": "SQ_INSTS_VALU per launch (profiles/pmc_%s.json) / (512 wave-instructions per "
                           "cycle x 2.4 GHz x duration)" % workload}
 
 
