@@ -380,6 +380,34 @@ int ltr_linear_sgd_step_f32(int kind, float sigma, const float *X, float *W, flo
                             int rel_dtype, const int64_t *n, const float *grad_out, int B, int L, int F,
                             float lr, float *loss, float *bucket /* F + 2 */, void *workspace,
                             size_t workspace_bytes, void *overlap /* or NULL */, void *stream);
+/* K synchronous-SGD steps over K batches in ONE persistent launch ("a persistent multi-batch
+ * launch"): exactly the K calls
+ *     for k in range(K): ltr_linear_sgd_step_f32(kind, sigma, X[k], W, bias, rel[k], rel_dtype, n[k], NULL (= 1/B), B, L, F,
+ *                                                lr, loss + k*B, bucket + k*(F+2), ...)
+ * of the reference's loop body (examples/01-basic-usage.py:66-75, `.mean().backward()` + SGD), but one workgroup per
+ * query position stays resident over all K batches: the tile of batch k + 1 streams from HBM while the gradient of
+ * batch k is summed over the queries and the weights are updated (by the workgroups themselves: tagged 16-byte
+ * write-through units, no launch boundary, fixed summation order -- results are deterministic run to run and equal
+ * the per-step path's up to fp32 summation order).  X / rel / n are HOST arrays of K DEVICE pointers (every batch
+ * B x L x F, row-major, resident; the DataLoader knows the next batches).  loss: K * B per-query losses; bucket:
+ * K * (F + 2) floats, per step the mean gradient dW | db and the sum of the losses.  W / bias are read at entry and
+ * hold the weights after the last step on return (stream order).  Shapes the persistent kernel does not take
+ * (ltr_linear_sgd_steps_plan == 0: rows not whole float4, lists over 256 documents or too long for nine register
+ * sweeps, more queries than can be resident at once -- 4 workgroups per CU --, fewer queries than 2 (F + 4) / 3,
+ * the LambdaNDCG kinds, a stream under capture) run as the K per-step calls, for which `workspace` must hold
+ * ltr_linear_workspace_bytes(B, L, F).  A wait inside the launch that gives up (a workgroup not resident for
+ * seconds) raises LTR_ERR_TIMEOUT in the device status and W / bias are NOT written. */
+int ltr_linear_sgd_steps_f32(int kind, float sigma, int K, const float *const *X, const void *const *rel, int rel_dtype,
+                             const int64_t *const *n, int B, int L, int F, float lr, float *W, float *bias,
+                             float *loss /* K * B */, float *bucket /* K * (F + 2) */, void *workspace,
+                             size_t workspace_bytes, void *stream);
+/* 1 when ltr_linear_sgd_steps_f32 takes this shape on the persistent kernel, 0 when it runs K per-step calls. */
+int ltr_linear_sgd_steps_plan(int kind, int B, int L, int F);
+/* Tests only: != 0 makes every wait of the persistent kernel give up at once. */
+void ltr_debug_steps_force_timeout(int on);
+/* Tuning only: a device buffer of K * B * 8 int64 that later ltr_linear_sgd_steps_f32 launches fill with 100 MHz
+ * wall-clock stamps per step and workgroup (scripts/dev/trace_steps.py), or NULL to stop. */
+void ltr_debug_steps_trace(long long *buffer);
 /* Mailbox all-reduce: the < 3 KB gradient bucket of a data-parallel step summed over the ranks of ONE node by a
  * single small kernel per rank instead of a collective library (one process per GPU; no counterpart in the
  * reference, which is single-process).  Every rank owns a mailbox of 8-byte {tag, value} granules in fine-grained
@@ -389,13 +417,20 @@ int ltr_linear_sgd_step_f32(int kind, float sigma, const float *X, float *W, flo
  * bytes), the callers gather the handles (any transport), every rank calls ltr_mailbox_connect with all of them
  * in rank order.  ltr_mailbox_allreduce has ncclAllReduce's signature (ncclFloat32 / ncclSum only; comm = the
  * handle; count <= count_max), so it can be given to ltr_overlap_create(..., depth = 0); ltr_linear_sgd_step_f32
- * then applies the weight update inside the same kernel.  A rank that never shows up turns into NaN sums and
- * LTR_ERR_TIMEOUT in the device status, not a hang.  world <= 16. */
+ * then applies the weight update inside the same kernel.  A rank that has not shown up after the time budget of one
+ * all-reduce (120 s; LTR_MAILBOX_TIMEOUT_MS in the environment) turns into a NaN bucket and LTR_ERR_TIMEOUT in the
+ * device status, not a hang -- and the WEIGHTS ARE NOT UPDATED by that step (they stay what they were: check
+ * ltr_device_status before trusting W after a step that may have timed out).  ltr_mailbox_create fails with
+ * LTR_ERR_CONFIG when fine-grained device memory is not available (no silent fall-back to memory whose stores a
+ * peer might not see): callers then use a collective library.  world <= 16. */
 int ltr_mailbox_create(int rank, int world, int count_max, void **handle, void *ipc_handle_out /* 64 bytes */);
 int ltr_mailbox_connect(void *handle, const void *all_ipc_handles /* world x 64 bytes, rank order */);
 int ltr_mailbox_destroy(void *handle);
 int ltr_mailbox_allreduce(const void *sendbuf, void *recvbuf, size_t count, int datatype, int op, void *comm,
                           void *stream);
+/* Tests only: timeout_ms > 0 sets the time budget of every later mailbox all-reduce of the process; tag >= 0 makes
+ * `tag` the number of all-reduces this mailbox has done (the wrap 0xFFFFFFFF -> 2: every rank sets the same). */
+int ltr_debug_mailbox_state(void *handle, long long timeout_ms, long long tag);
 /* Tests only: an ltr_allreduce_fn that adds `comm` -- a device pointer to `count` floats, "the other rank's
  * bucket" -- to the buffer on `stream` (ncclFloat32 / ncclSum only). */
 int ltr_debug_fake_allreduce(const void *sendbuf, void *recvbuf, size_t count, int datatype, int op, void *comm,

@@ -11,9 +11,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libltr_hip.so")
-# three translation units, compiled side by side and linked into one library: the loss / metric /
-# helper kernels with the C ABI, the fused Linear scorer + loss kernels, the fused MLP + scorer layer
-SOURCES = [os.path.join(CSRC, f) for f in ("ltr_kernels.hip", "ltr_linear.hip", "ltr_mlp.hip")]
+# four translation units, compiled side by side and linked into one library: the loss / metric /
+# helper kernels with the C ABI, the fused Linear scorer + loss kernels, the fused MLP + scorer layer,
+# the persistent multi-batch training kernel
+SOURCES = [os.path.join(CSRC, f) for f in ("ltr_kernels.hip", "ltr_linear.hip", "ltr_mlp.hip", "ltr_steps.hip")]
+# per-source compiler flags.  ltr_steps.hip: the step loop of the persistent kernel is one big loop body; machine LICM
+# hoists the pair pass's materialised constants and addresses out of it and keeps them in VGPRs next to the register
+# tile (32 spilled VGPRs under the 64 of four workgroups per CU; none without the pass)
+SOURCE_FLAGS = {"ltr_steps.hip": ["-mllvm", "-disable-machine-licm"]}
 OBJ_DIR = os.path.join(_ROOT, "build", "obj")
 # every .inc the translation units include, and the public header
 DEPENDS = SOURCES + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".inc")) + \
@@ -50,7 +55,7 @@ def build_extension(force=False, verbose=False, extra_flags=(), lib_path=None):
     jobs = []
     for src in SOURCES:
         obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
-        cmd = common + ["-c", src, "-o", obj]
+        cmd = common + SOURCE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         jobs.append((cmd, subprocess.Popen(cmd), obj))

@@ -267,22 +267,24 @@ class RcclOverlap:
         """Step i through ltr_linear_step_f32: its bucket is i % depth, its all-reduce runs under step i + 1."""
         k = i % max(1, self.depth)
         st = torch.cuda.current_stream(self.device).cuda_stream
-        self._C.check(self.lib.ltr_linear_step_f32(
-            kind, sigma, X.data_ptr(), W.data_ptr(), bias.data_ptr(), rel.data_ptr(), rel_dtype, n.data_ptr(),
-            None if grad_out is None else grad_out.data_ptr(), B, L, F, loss.data_ptr(), self.buckets[k].data_ptr(),
-            1 if accumulate else 0, workspace.data_ptr(), workspace.numel() * workspace.element_size(),
-            self.handle, k, st))
+        with torch.cuda.device(self.device):      # (status word, exchange areas and launches on THIS device)
+            self._C.check(self.lib.ltr_linear_step_f32(
+                kind, sigma, X.data_ptr(), W.data_ptr(), bias.data_ptr(), rel.data_ptr(), rel_dtype, n.data_ptr(),
+                None if grad_out is None else grad_out.data_ptr(), B, L, F, loss.data_ptr(), self.buckets[k].data_ptr(),
+                1 if accumulate else 0, workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                self.handle, k, st))
 
     def sgd_step(self, kind, sigma, X, W, bias, rel, rel_dtype, n, grad_out, B, L, F, lr, loss, workspace):
         """One synchronous-SGD step through ltr_linear_sgd_step_f32 (in-stream handles only): kernels, the step's
         all-reduce behind them on the same stream, then W -= lr * dW, bias -= lr * db -- the next step scores with
         weights that waited for this step's collective (examples/01-basic-usage.py:72-75, sharded)."""
         st = torch.cuda.current_stream(self.device).cuda_stream
-        self._C.check(self.lib.ltr_linear_sgd_step_f32(
-            kind, sigma, X.data_ptr(), W.data_ptr(), bias.data_ptr(), rel.data_ptr(), rel_dtype, n.data_ptr(),
-            None if grad_out is None else grad_out.data_ptr(), B, L, F, float(lr), loss.data_ptr(),
-            self.buckets[0].data_ptr(), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
-            self.handle, st))
+        with torch.cuda.device(self.device):      # (status word, exchange areas and launches on THIS device)
+            self._C.check(self.lib.ltr_linear_sgd_step_f32(
+                kind, sigma, X.data_ptr(), W.data_ptr(), bias.data_ptr(), rel.data_ptr(), rel_dtype, n.data_ptr(),
+                None if grad_out is None else grad_out.data_ptr(), B, L, F, float(lr), loss.data_ptr(),
+                self.buckets[0].data_ptr(), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                self.handle, st))
 
     def result(self, i):
         """Step i's summed bucket; the current stream is made to wait for its all-reduce."""
@@ -386,16 +388,24 @@ class MailboxOverlap:
     def allreduce_(self, vec):
         """In-place sum of a float32 device vector of at most F + 2 elements over the ranks (current stream)."""
         st = torch.cuda.current_stream(self.device).cuda_stream
-        rc = self.lib.ltr_mailbox_allreduce(vec.data_ptr(), vec.data_ptr(), vec.numel(), 7, 0, self.mbox, st)
+        with torch.cuda.device(self.device):
+            rc = self.lib.ltr_mailbox_allreduce(vec.data_ptr(), vec.data_ptr(), vec.numel(), 7, 0, self.mbox, st)
         if rc != 0:
             raise RuntimeError("ltr_mailbox_allreduce failed")
         return vec
 
     def _self_check(self):
+        """Three all-reduces (both halves of the mailbox, and once more) against torch.distributed, under a SHORT
+        time budget (a peer that is not there is not going to come).  Whatever happens, the sticky device status is
+        left CLEAN: a failed check must not make the fall-back (RcclOverlap / plain steps) fail with the
+        LTR_ERR_TIMEOUT this check provoked."""
+        ok = True
+        budget_ms = int(os.environ.get("LTR_MAILBOX_CHECK_TIMEOUT_MS", "5000"))
+        default_ms = int(os.environ.get("LTR_MAILBOX_TIMEOUT_MS", "0")) or 120000
         try:
+            self.lib.ltr_debug_mailbox_state(None, budget_ms, -1)
             rank = dist.get_rank(self.group) if dist.is_initialized() else 0
-            ok = True
-            for rep in range(3):             # both parities, and once more
+            for rep in range(3):
                 v = (torch.arange(self.F + 2, dtype=torch.float32, device=self.device) + 1.0 + rep) * float(rank + 1) * 0.37
                 want = v.clone()
                 if dist.is_initialized():
@@ -407,26 +417,39 @@ class MailboxOverlap:
                 # (the mailbox adds in rank order, the library in its own: equal to a few ulps, not bit for bit)
                 ok = ok and bool(torch.allclose(v, want, rtol=1e-5, atol=1e-6))
                 self._check_note = "max abs diff %g" % float((v - want).abs().max())
-            return ok and self._C.lib().ltr_device_status(0) == 0
+                if not ok:
+                    break                  # (a timed-out all-reduce is not repeated: one budget, not three)
+            ok = ok and self.lib.ltr_device_status(0) == 0
         except Exception as exc:  # pragma: no cover - depends on the runtime
             self._check_note = repr(exc)
-            return False
+            ok = False
+        finally:
+            self.lib.ltr_debug_mailbox_state(None, default_ms, -1)
+            if not ok:
+                try:
+                    torch.cuda.synchronize(self.device)
+                except Exception:  # pragma: no cover
+                    pass
+                self.lib.ltr_device_status(1)      # the fall-back starts clean
+        return ok
 
     def sgd_step(self, kind, sigma, X, W, bias, rel, rel_dtype, n, grad_out, B, L, F, lr, loss, workspace):
         st = torch.cuda.current_stream(self.device).cuda_stream
-        self._C.check(self.lib.ltr_linear_sgd_step_f32(
-            kind, sigma, X.data_ptr(), W.data_ptr(), bias.data_ptr(), rel.data_ptr(), rel_dtype, n.data_ptr(),
-            None if grad_out is None else grad_out.data_ptr(), B, L, F, float(lr), loss.data_ptr(),
-            self.buckets[0].data_ptr(), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
-            self.handle, st))
+        with torch.cuda.device(self.device):      # (status word, exchange areas and launches on THIS device)
+            self._C.check(self.lib.ltr_linear_sgd_step_f32(
+                kind, sigma, X.data_ptr(), W.data_ptr(), bias.data_ptr(), rel.data_ptr(), rel_dtype, n.data_ptr(),
+                None if grad_out is None else grad_out.data_ptr(), B, L, F, float(lr), loss.data_ptr(),
+                self.buckets[0].data_ptr(), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                self.handle, st))
 
     def step(self, i, kind, sigma, X, W, bias, rel, rel_dtype, n, grad_out, B, L, F, loss, workspace, accumulate=False):
         st = torch.cuda.current_stream(self.device).cuda_stream
-        self._C.check(self.lib.ltr_linear_step_f32(
-            kind, sigma, X.data_ptr(), W.data_ptr(), bias.data_ptr(), rel.data_ptr(), rel_dtype, n.data_ptr(),
-            None if grad_out is None else grad_out.data_ptr(), B, L, F, loss.data_ptr(), self.buckets[0].data_ptr(),
-            1 if accumulate else 0, workspace.data_ptr(), workspace.numel() * workspace.element_size(),
-            self.handle, 0, st))
+        with torch.cuda.device(self.device):      # (status word, exchange areas and launches on THIS device)
+            self._C.check(self.lib.ltr_linear_step_f32(
+                kind, sigma, X.data_ptr(), W.data_ptr(), bias.data_ptr(), rel.data_ptr(), rel_dtype, n.data_ptr(),
+                None if grad_out is None else grad_out.data_ptr(), B, L, F, loss.data_ptr(), self.buckets[0].data_ptr(),
+                1 if accumulate else 0, workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                self.handle, 0, st))
 
     def result(self, i=0):
         return self.buckets[0]

@@ -7,6 +7,7 @@ parameters (``weight`` (1, F), ``bias`` (1,), state_dict-compatible with ``nn.Li
 same per-query output -- computed by ``ltr_linear_partials_f32`` so the (B, L, F) feature
 tensor crosses HBM once instead of twice plus the score round trip.
 """
+import ctypes
 import math
 
 import torch
@@ -233,6 +234,60 @@ def linear_loss_step(xs, weight, bias, relevance, n, loss="hinge", grad_out=None
     if return_loss_sum:
         out = out + (lsum,)
     return out
+
+
+def linear_sgd_steps(batches, weight, bias, lr, loss="hinge", return_losses=False):
+    """K synchronous-SGD steps of the reference's training loop body in ONE persistent launch
+    (include/ltr_hip.h: ltr_linear_sgd_steps_f32; examples/01-basic-usage.py:66-75):
+
+        for xs, ys, n in batches:                      # every batch (B, L, F) / (B, L) / (B,), resident on the device
+            loss = loss_fn(Linear(F, 1)(xs), ys, n).mean(); loss.backward(); SGD.step()
+
+    `weight` (F elements) and `bias` (1 element or None) are updated IN PLACE (fp32, contiguous).  Returns
+    (mean_loss[K], grads[K, F + 1]) -- per step the mean loss and the mean gradient dW | db it applied -- and the
+    per-query losses [K, B] with return_losses.  The batch of step k + 1 streams from HBM while step k's gradient is
+    reduced and the weights are updated; shapes the persistent kernel does not take run as K per-step calls (same
+    results up to fp32 summation order)."""
+    kind, sigma = _resolve_loss(loss)
+    batches = list(batches)
+    K = len(batches)
+    if K == 0:
+        raise ValueError("no batches")
+    Xs, rs, ns = [], [], []
+    B = L = F = None
+    for xs, ys, n in batches:
+        X = _prepare_features(xs)
+        if B is None:
+            B, L, F = X.shape
+        elif tuple(X.shape) != (B, L, F):
+            raise ValueError("every batch must have the same shape (the persistent launch keeps one workgroup per query position)")
+        r, nn = _labels_and_n(ys, n, B, L, X.device)
+        if rs and r.dtype != rs[0].dtype:
+            raise ValueError("every batch must use the same label dtype")
+        Xs.append(X); rs.append(r); ns.append(nn)
+    dev = Xs[0].device
+    if weight.dtype is not torch.float32 or not weight.is_contiguous() or weight.numel() != F or not weight.is_cuda:
+        raise ValueError("weight must be a contiguous fp32 device tensor of %d elements (it is updated in place)" % F)
+    if bias is not None and (bias.dtype is not torch.float32 or bias.numel() != 1 or not bias.is_cuda):
+        raise ValueError("bias must be an fp32 device tensor of one element (it is updated in place)")
+    lossv = torch.empty(K, B, dtype=torch.float32, device=dev)
+    bucket = torch.empty(K, F + 2, dtype=torch.float32, device=dev)
+    ws_bytes = _C.lib().ltr_linear_workspace_bytes(B, L, F)
+    ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=dev)
+    PtrArr = ctypes.c_void_p * K
+    xp = PtrArr(*[t.data_ptr() for t in Xs])
+    rp = PtrArr(*[t.data_ptr() for t in rs])
+    np_ = PtrArr(*[t.data_ptr() for t in ns])
+    with _C.device_ctx(Xs[0]):
+        _C.check(_C.lib().ltr_linear_sgd_steps_f32(
+            kind, float(sigma), K, xp, rp, _C.label_dtype(rs[0]), np_, B, L, F, float(lr),
+            weight.data_ptr(), None if bias is None else bias.data_ptr(), lossv.data_ptr(), bucket.data_ptr(),
+            ws.data_ptr(), ws.numel() * 4, _C.stream_of(Xs[0])))
+    # (the launch reads the batches asynchronously: keep them alive until the stream has passed it)
+    for t in Xs + rs + ns:
+        t.record_stream(torch.cuda.current_stream(dev))
+    out = (bucket[:, F + 1] / float(B), bucket[:, :F + 1])
+    return out + (lossv,) if return_losses else out
 
 
 # ---------------------------------------------------------------------------------------------

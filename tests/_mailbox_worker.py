@@ -25,8 +25,34 @@ def main():
     out = {"rank": rank}
     B, L, F, kind = 96, 128, 136, "hinge"
     lo, hi = shard_bounds(B, rank, world)
+    lib = _C.lib()
+    force_fail = os.environ.get("MAILBOX_FORCE_FAIL") == "1"
+    if force_fail:
+        lib.ltr_debug_force_timeout(1)                   # every in-launch wait gives up at once: the self-check must fail
     mb = MailboxOverlap(F, count=hi - lo, device=dev)
     out["ok"], out["why"] = bool(mb.ok), mb.why
+    if force_fail:
+        # a failed self-check must leave the process usable -- status clean, plain steps run and are right
+        lib.ltr_debug_force_timeout(0)
+        out["status_after_failed_check"] = int(lib.ltr_device_status(0))
+        s, y, n, X, W, b = synth(B, L, 21, F=F)
+        Xd, yd, nd, Wd, bd = X.to(dev), y.to(dev), n.to(dev), W.clone().to(dev), b.clone().to(dev)
+        ws = torch.empty(lib.ltr_linear_workspace_bytes(B, L, F) // 4 + 64, device=dev)
+        loss = torch.empty(B, device=dev)
+        bucket = torch.zeros(F + 3, device=dev)
+        rc = lib.ltr_linear_sgd_step_f32(_C.HINGE, 1.0, Xd.data_ptr(), Wd.data_ptr(), bd.data_ptr(), yd.data_ptr(), _C.LABEL_I64,
+                                         nd.data_ptr(), None, B, L, F, 0.05, loss.data_ptr(), bucket.data_ptr(), ws.data_ptr(),
+                                         ws.numel() * 4, None, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        _, _, dW, db = O.linear_pairwise(kind, X.numpy(), W.numpy(), float(b[0]), y.numpy(), n.numpy(), np.full(B, 1.0 / B))
+        want = (W.double() - 0.05 * torch.from_numpy(dW)).float()
+        out["fallback_rc"] = int(rc)
+        out["fallback_step_ok"] = bool(np.allclose(Wd.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-5))
+        mb.close()
+        print(json.dumps(out), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if not mb.ok:
         print(json.dumps(out), flush=True)
         dist.barrier()
@@ -36,7 +62,15 @@ def main():
     busy = torch.randn(2048, 2048, device=dev)
     bad = 0
     same = True
-    for it in range(60):
+    rounds = 60 if world <= 2 else 24
+    for it in range(rounds):
+        if it == rounds // 2:
+            # the tag wrap: 0xFFFFFFFD -> ... -> 0xFFFFFFFF -> 2 (0 and 1 skipped so that the halves keep alternating;
+            # round 4 wrapped to 1 and used one half twice in a row -- VERDICT r4 weak 1c)
+            torch.cuda.synchronize()
+            dist.barrier()
+            lib.ltr_debug_mailbox_state(mb.mbox, 0, 0xFFFFFFFC)
+            dist.barrier()
         g = torch.Generator().manual_seed(1000 * it)
         vecs = [torch.randn(F + 2, generator=g) * (r + 1) for r in range(world)]
         want = vecs[0].clone()
@@ -63,7 +97,6 @@ def main():
     Xd, yd, nd = X[lo:hi].to(dev), y[lo:hi].to(dev), n[lo:hi].to(dev)
     Wd, bd = W.clone().to(dev), b.clone().to(dev)
     go = torch.full((hi - lo,), 1.0 / B, device=dev)
-    lib = _C.lib()
     ws = torch.empty(lib.ltr_linear_workspace_bytes(hi - lo, L, F) // 4 + 64, device=dev)
     loss = torch.empty(hi - lo, device=dev)
     lr = 0.05
@@ -81,6 +114,28 @@ def main():
     dist.all_gather_object(gathered, Wd.cpu().numpy().tobytes())
     out["weights_identical_across_ranks"] = all(g_ == gathered[0] for g_ in gathered)
     out["status"] = int(lib.ltr_device_status(0))
+    # ---- a step whose all-reduce times out: bucket poisoned, status raised, WEIGHTS UNTOUCHED ----
+    torch.cuda.synchronize()
+    dist.barrier()
+    before = Wd.clone()
+    lib.ltr_debug_force_timeout(1)
+    rc = lib.ltr_linear_sgd_step_f32(_C.HINGE, 1.0, Xd.data_ptr(), Wd.data_ptr(), bd.data_ptr(), yd.data_ptr(), _C.LABEL_I64,
+                                     nd.data_ptr(), go.data_ptr(), hi - lo, L, F, lr, loss.data_ptr(), mb.buckets[0].data_ptr(),
+                                     ws.data_ptr(), ws.numel() * 4, mb.handle, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    lib.ltr_debug_force_timeout(0)
+    out["timeout_step_rc"] = int(rc)
+    out["timeout_status"] = int(lib.ltr_device_status(1))
+    out["timeout_weights_untouched"] = bool(torch.equal(before, Wd)) and bool(torch.isfinite(Wd).all())
+    out["timeout_bucket_poisoned"] = bool(torch.isnan(mb.buckets[0][:F + 2]).all())
+    dist.barrier()
+    # (the forced give-up skipped the polls but every rank still SENT its granules and advanced its tag: the mailboxes
+    # are in step, the next all-reduce is a normal one)
+    v = torch.full((F + 2,), float(rank + 1), device=dev)
+    mb.allreduce_(v)
+    torch.cuda.synchronize()
+    out["after_timeout_allreduce_ok"] = bool(torch.equal(v.cpu(), torch.full((F + 2,), float(world * (world + 1) // 2))))
+    out["status_end"] = int(lib.ltr_device_status(0))
     mb.close()
     print(json.dumps(out), flush=True)
     dist.barrier()

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from oracle import ltr_oracle as O
-from tests.conftest import synth
+from tests.conftest import assert_rank_dependent_losses, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -64,18 +64,16 @@ def _run(kind, B, L, F, seed, want_plan, busy=False):
     for o in outs[1:]:
         for got, first in zip(o, outs[0]):
             assert np.array_equal(got, first), "runs differ (kernel must be deterministic)"
-    want_l, _, want_dW, want_db = O.linear_pairwise(kind, X.numpy(), W.numpy(), float(b[0]), y.numpy(),
-                                                    n.numpy(), np.full(B, 1.0 / B))
+    want_l, want_s, want_dW, want_db = O.linear_pairwise(kind, X.numpy(), W.numpy(), float(b[0]), y.numpy(),
+                                                         n.numpy(), np.full(B, 1.0 / B))
     loss, dW, db = outs[0]
     assert np.all(np.isfinite(loss))
-    ok = np.isclose(loss, want_l, rtol=5e-4, atol=1e-5)                # every row
     if kind in ("ndcg1", "ndcg2"):
-        # fp32 scores can order two nearly tied documents of a long list the other way round than the fp64 oracle's
-        # scores do: one swapped pair of ranks moves that row's loss by ~1e-3 (the general kernel shows the same
-        # rows: scripts/dev/dbg_ndcg_parts.py) -- a few rows at most, and within 5e-3
-        assert ok.mean() >= 0.97 and np.allclose(loss, want_l, rtol=5e-3, atol=1e-5)
+        # every row at 5e-4, a row that is off against the fp64 scores must be a TESTED rank flip of nearly tied fp32
+        # scores (tests/conftest.py: assert_rank_dependent_losses) -- rounds 3-4 waved 3 % of the rows through at 5e-3
+        assert_rank_dependent_losses(kind, loss, X, W, b, y, n, want_l, want_s, rtol=5e-4)
     else:
-        assert ok.all()
+        assert np.isclose(loss, want_l, rtol=5e-4, atol=1e-5).all()               # every row
     tol = 2e-4 * max(1.0, float(np.max(np.abs(want_dW))))
     assert np.max(np.abs(dW - want_dW)) < tol
     assert abs(float(db[0]) - want_db) < tol
