@@ -821,11 +821,51 @@ def main():
                  "ms_per_step": median(r0) / max(1, steps_timed // 2) * 1e3,
                  "what": "ltr_linear_step_f32: the same two launches, W left alone (rounds 1-3 reported this)"}
 
+    # the persistent multi-batch launch of SURVEY.md 8(d): the SAME steps (same rotating batches, same SGD update) as K-step
+    # launches of ltr_linear_sgd_steps_f32 -- one workgroup per query position resident over the batches, the reduction and
+    # the update done in-kernel, the next tile streaming under them (csrc/ltr_steps.inc; EXPERIMENTS.md round 5)
+    persistent = None
+    if dist is None:
+        try:
+            import ctypes
+            lib = fs.lib
+            plan = int(lib.ltr_linear_sgd_steps_plan(fs.kind_id, B, L, F))
+            Kp = 256
+            Parr = ctypes.c_void_p * Kp
+            xp = Parr(*[batches[k % nbuf]["X"].data_ptr() for k in range(Kp)])
+            rp = Parr(*[batches[k % nbuf]["rel"].data_ptr() for k in range(Kp)])
+            npp = Parr(*[batches[k % nbuf]["n"].data_ptr() for k in range(Kp)])
+            p_loss = torch.empty(Kp, B, device=dev)
+            p_bucket = torch.empty(Kp, F + 2, device=dev)
+            Wp, bp = fs.W.clone(), fs.bias.clone()
+
+            def pstep(i):
+                rc = lib.ltr_linear_sgd_steps_f32(fs.kind_id, 1.0, Kp, xp, rp, fs._C.LABEL_I64, npp, B, L, F, SGD_LR, Wp.data_ptr(),
+                                                  bp.data_ptr(), p_loss.data_ptr(), p_bucket.data_ptr(), fs.part.data_ptr(),
+                                                  fs.ws_bytes, fs._stream())
+                if rc:
+                    fs._C.check(rc)
+            for i in range(2):
+                pstep(i)
+            nl = max(2, steps_timed // Kp)
+            rps = time_region(pstep, nl, barrier, repeats=5, reduce_max=reduce_max)
+            tp = median(rps) / (nl * Kp)
+            persistent = {"entry_point": "ltr_linear_sgd_steps_f32", "plan_persistent_kernel": plan, "steps_per_launch": Kp,
+                          "launches_timed": nl, "us_per_step": tp * 1e6, "queries_per_s": B / tp,
+                          "per_step_call_us": elapsed / steps_timed * 1e6,
+                          "step_level_frac_of_hbm_peak": None,
+                          "what": "the same synchronous-SGD steps over the same rotating batches in K-step persistent launches "
+                                  "(in-kernel reduction + update, next tile streams under them); `value` stays the per-step call"}
+        except Exception as exc:  # pragma: no cover
+            persistent = {"error": repr(exc)[:200]}
+
     out = None
     if rank == 0:
         extra = {"timed_regions_s": regions, "steps_per_region": steps_timed}
         if noupd is not None:
             extra["step_without_weight_update"] = noupd
+        if persistent is not None:
+            extra["persistent_multi_batch"] = persistent
         _ = pmc_record(args.workload)
         extra["pmc_counters"] = ("profiles/pmc_<workload>.json (separate rocprofv3 --pmc passes); refused when the kernel "
                                  "sources changed since: stale for %s" % (sorted(PMC_STALE) or "none"))
@@ -856,6 +896,13 @@ def main():
                                "note": "SURVEY.md 8(d) bytes (padded rows counted although never read)"},
             "valu_issue_frac": valu_frac(pmc.get("valu_insts_per_launch"), k_us),
         }
+        # the same bytes against the whole STEP (kernel + reduction launch + update): what HBM delivers per step
+        step_s = elapsed / steps_timed
+        roofline["step_level"] = {"us_per_step": step_s * 1e6, "frac": moved / step_s / 1e9 / HBM_PEAK_GBS,
+                                  "note": "must-move bytes / whole-step time / 8 TB/s (the per-kernel frac leaves the reduction "
+                                          "launch and the launch boundaries out)"}
+        if persistent is not None and "us_per_step" in persistent:
+            persistent["step_level_frac_of_hbm_peak"] = moved / (persistent["us_per_step"] * 1e-6) / 1e9 / HBM_PEAK_GBS
         # what ONE ROUND of workgroups can stream at this batch size: the same grid, workgroup size and
         # ragged spans with nothing behind the loads (ltr_debug_stream_probe_f32)
         if fs.plan == "linear_regtile_kernel" and L * (F // 4) <= 19 * 512 and F % 4 == 0:

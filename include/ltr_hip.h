@@ -322,6 +322,10 @@ int ltr_linear_partials_f32(int kind, float sigma, const float *X, const float *
                             float *scores_out, float *partials /* (B, PF) */, void *stream);
 int ltr_linear_reduce_f32(const float *partials, const float *grad_out, int B, int F, float *dW,
                           float *db, void *stream);
+/* The same with ONE upstream gradient for every query, read from device memory: dW_f = scale[0] * sum_b partials[b, f]
+ * -- what autograd hands the backward of `.mean()` / `.sum()` (an expanded scalar): no (B,) copy of it is made. */
+int ltr_linear_reduce_bcast_f32(const float *partials, const float *scale /* device scalar */, int B, int F, float *dW,
+                                float *db, void *stream);
 /* Same reduction, additionally writing loss_sum[0] = sum_b loss[b] (the scalar a training loop
  * logs / all-reduces) in the same launch.  loss_sum may be NULL. */
 int ltr_linear_reduce_loss_f32(const float *partials, const float *grad_out, const float *loss,

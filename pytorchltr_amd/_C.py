@@ -87,6 +87,7 @@ SIGNATURES = {
     "ltr_linear_partials_f32": (_i, [_i, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i,
                                      _vp, _vp, _vp, _vp]),
     "ltr_linear_reduce_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "ltr_linear_reduce_bcast_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "ltr_linear_reduce_loss_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "ltr_linear_reduce_accum_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "ltr_linear_scores_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -136,6 +136,14 @@ class PairwiseLossFunction(torch.autograd.Function):
 
 
 def pairwise_loss(scores, relevance, n, kind, sigma=1.0):
+    # scores that have not been computed yet (fused.LazyScores, what LinearScorer returns in a training step): scores,
+    # loss and weight-gradient rows in ONE pass over the features instead of scorer kernel + loss kernel + gradient kernel
+    fused = getattr(scores, "fused_loss", None)
+    if fused is not None:
+        out = fused(relevance, n, kind, sigma)
+        if out is not None:
+            return out
+        scores = scores.materialize()
     return PairwiseLossFunction.apply(scores, relevance, n, kind, sigma)
 
 

@@ -126,19 +126,38 @@ class _LinearLossFunction(torch.autograd.Function):
         (ws,) = ctx.saved_tensors
         B, F = ctx.dims
         go = grad_loss
-        if go.dtype is not torch.float32 or go.dim() != 1 or not go.is_contiguous():
-            go = go.reshape(B).float().contiguous()
         dW = torch.empty(ctx.w_shape, dtype=torch.float32, device=ws.device)
         db = torch.empty(1, dtype=torch.float32, device=ws.device)
+        # `.mean().backward()` / `.sum().backward()`: autograd hands over an expanded scalar (stride 0) -- the reduction
+        # reads it where it is instead of a (B,) copy being made first
+        bcast = go.dtype is torch.float32 and go.dim() == 1 and go.stride(0) == 0
+        if not bcast and (go.dtype is not torch.float32 or go.dim() != 1 or not go.is_contiguous()):
+            go = go.reshape(B).float().contiguous()
         with _C.device_ctx(ws):
-            rc = _C.lib().ltr_linear_reduce_f32(ws.data_ptr(), go.data_ptr(), B, F, dW.data_ptr(),
-                                                db.data_ptr(), _C.stream_of(ws))
+            entry = _C.lib().ltr_linear_reduce_bcast_f32 if bcast else _C.lib().ltr_linear_reduce_f32
+            rc = entry(ws.data_ptr(), go.data_ptr(), B, F, dW.data_ptr(), db.data_ptr(), _C.stream_of(ws))
             if rc != 0:
                 _C.check(rc)
         return (None, dW, db if ctx.has_bias else None, None, None, None, None, None)
 
 
 _pieces_cache = {}
+
+
+def _prefer_pieces(kind, B, L, F):
+    """True where the three-kernel pieces (streaming scorer, split-query loss, streaming weight gradient) beat the
+    one-kernel fused path: a few long lists that neither the cluster nor the parts kernel takes (cached per shape)."""
+    key = (kind, B, L, F)
+    v = _pieces_cache.get(key)
+    if v is None:
+        v = False
+        if B > 0 and _C.lib().ltr_pairwise_loss_workspace_bytes(kind, B, L) != 0 and \
+                _C.lib().ltr_linear_fused_plan(kind, B, L, F) not in (_C.PLAN_CLUSTER, _C.PLAN_PARTS):
+            cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+            heavy_pairs = kind not in (_C.HINGE, _C.DCG_HINGE)
+            v = (2 * B <= cus) or (heavy_pairs and B <= cus and L > 768)
+        _pieces_cache[key] = v
+    return v
 
 
 class FusedLinearLoss(torch.nn.Module):
@@ -174,30 +193,14 @@ class FusedLinearLoss(torch.nn.Module):
                                          self.sigma, bool(return_scores))
 
     def _pieces_cached(self, B, L):
-        key = (self.kind, B, L, self.in_features)
-        v = _pieces_cache.get(key)
-        if v is None:
-            v = _pieces_cache[key] = bool(self._prefer_pieces(B, L))
-        return v
-
-    def _prefer_pieces(self, B, L):
         # measured on MI355X, fused kernel -> pieces, us (B x L x F; hinge / logistic / LambdaNDCG2):
         #   32 x 1000 x 220:  78/136/173 -> 46/52/77      128 x 1000 x 220: 84/145/181 -> 55/66/93
         #   256 x 1000 x 220: 86/145/183 -> 87/113/147    384 x 1000 x 220: 90/149/186 -> 114/149/204
         #   128 x 600 x 136:  41/64/90 -> 39/47/72        256 x 600 x 136:  44/66/93 -> 48/60/89
-        if B <= 0 or _C.lib().ltr_pairwise_loss_workspace_bytes(self.kind, B, L) == 0:
-            return False
-        # the cluster kernel (features once, a query over several workgroups) beats the pieces
-        # wherever it applies: 32 x 1000 x 220 hinge 32 vs 46 us, logistic 43 vs 52 -- and so does the parts
-        # kernel (round 4, module forward + backward replayed, pieces vs fused: 64 x 512 x 700 LambdaNDCG2 91 vs 48 us,
-        # 100 x 1000 x 700 hinge 120 vs 78, LambdaNDCG1 149 vs 107, 80 x 700 x 512 LambdaNDCG2 88 vs 68)
-        if _C.lib().ltr_linear_fused_plan(self.kind, B, L, self.in_features) in (_C.PLAN_CLUSTER, _C.PLAN_PARTS):
-            return False
-        cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-        if 2 * B <= cus:
-            return True
-        heavy_pairs = self.kind not in (_C.HINGE, _C.DCG_HINGE)
-        return heavy_pairs and B <= cus and L > 768
+        # the cluster kernel (features once, a query over several workgroups) beats the pieces wherever it applies:
+        # 32 x 1000 x 220 hinge 32 vs 46 us, logistic 43 vs 52 -- and so does the parts kernel (round 4, module forward
+        # + backward replayed, pieces vs fused: 64 x 512 x 700 LambdaNDCG2 91 vs 48 us, 100 x 1000 x 700 hinge 120 vs 78)
+        return _prefer_pieces(self.kind, B, L, self.in_features)
 
 
 def linear_loss_step(xs, weight, bias, relevance, n, loss="hinge", grad_out=None,
@@ -339,16 +342,106 @@ class _LinearScoreFunction(torch.autograd.Function):
         return (gx, out[:F].reshape(ctx.w_shape), out[F:] if ctx.has_bias else None, None)
 
 
+class LazyScores(torch.Tensor):
+    """``Linear(F, 1)(xs)`` that has not been computed yet.
+
+    What :class:`LinearScorer` returns in a training step: a (B, L, 1) fp32 tensor -- shape, dtype and device answer
+    without any work -- that remembers ``(xs, weight, bias)``.  The loss modules of this package recognise it and run
+    the features-once fused kernel (scores, loss, gradient and the per-query weight-gradient rows in ONE pass over the
+    feature tile; ``.backward()`` is then the cross-query reduction straight into ``weight.grad`` / ``bias.grad``): the
+    unchanged user script ``loss_fn(model(xs), ys, n).mean().backward()`` (examples/01-basic-usage.py:66-75,
+    docs/source/getting-started.rst:86-101) reaches the kernel that ``FusedLinearLoss`` reaches.  Anybody else who
+    touches the tensor -- a metric, ``.detach()``, arithmetic, ``print`` -- gets the real scores: they are computed by
+    the streaming scorer kernel on first use (autograd-connected to the layer's parameters) and kept."""
+
+    @staticmethod
+    def __new__(cls, xs, weight, bias, n):
+        r = torch.Tensor._make_wrapper_subclass(cls, (xs.shape[0], xs.shape[1], 1), dtype=torch.float32, device=xs.device)
+        r._xs, r._weight, r._bias, r._n = xs, weight, bias, n
+        r._real = None
+        r._versions = (weight._version, -1 if bias is None else bias._version)
+        return r
+
+    def materialize(self):
+        """The real (B, L, 1) scores (computed once, autograd-connected to the layer's parameters)."""
+        if self._real is None:
+            self._check_versions()
+            self._real = _LinearScoreFunction.apply(self._xs, self._weight, self._bias, self._n)
+        return self._real
+
+    def _check_versions(self):
+        if self._versions != (self._weight._version, -1 if self._bias is None else self._bias._version):
+            raise RuntimeError("the scorer's parameters were modified in place between model(xs) and the first use of its "
+                               "scores; use the scores (or call .materialize()) before the optimizer step")
+
+    def fused_loss(self, relevance, n, kind, sigma):
+        """loss[b] of the pairwise loss `kind` on these scores, or None when the scores have to be computed anyway."""
+        if self._real is not None or kind == _LISTWISE_SOFTMAX:
+            return None
+        xs = self._xs
+        B, L, F = xs.shape
+        if _prefer_pieces(kind, B, L, F):
+            return None
+        self._check_versions()
+        return _LinearLossFunction.apply(xs, self._weight, self._bias, relevance, n, kind, sigma, False)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in _LAZY_METADATA:
+            if func == _REQUIRES_GRAD_GET:
+                a = args[0]
+                return bool(a._weight.requires_grad or (a._bias is not None and a._bias.requires_grad))
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+
+        def real(a):
+            if isinstance(a, LazyScores):
+                return a.materialize()
+            if isinstance(a, (list, tuple)):
+                return type(a)(real(v) for v in a)
+            return a
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*[real(a) for a in args], **{k: real(v) for k, v in kwargs.items()})
+
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        # (only reached by calls that bypass the Python API -- every torch function and Tensor method goes through
+        # __torch_function__ above, where autograd still sees the real scores)
+        def real(a):
+            if isinstance(a, LazyScores):
+                return a.materialize()
+            if isinstance(a, (list, tuple)):
+                return type(a)(real(v) for v in a)
+            return a
+        return func(*[real(a) for a in args], **{k: real(v) for k, v in (kwargs or {}).items()})
+
+
+_LISTWISE_SOFTMAX = 100                  # (_autograd.LISTWISE_SOFTMAX: not a pairwise kind, no fused kernel)
+_REQUIRES_GRAD_GET = torch.Tensor.requires_grad.__get__
+_LAZY_METADATA = {
+    torch.Tensor.shape.__get__, torch.Tensor.dtype.__get__, torch.Tensor.device.__get__, torch.Tensor.is_cuda.__get__,
+    torch.Tensor.ndim.__get__, torch.Tensor.layout.__get__, torch.Tensor.size, torch.Tensor.dim, torch.Tensor.numel,
+    torch.Tensor.nelement, torch.Tensor.ndimension, torch.Tensor.is_floating_point, torch.Tensor.is_complex,
+    torch.Tensor.get_device, _REQUIRES_GRAD_GET,
+}
+
+
 class LinearScorer(torch.nn.Module):
     """``torch.nn.Linear(in_features, 1)`` for (B, L, F) feature batches, state_dict-compatible
-    with it, computed by two HBM-streaming kernels instead of rocBLAS' one-column GEMM:
+    with it, computed by HBM-streaming kernels instead of rocBLAS' one-column GEMM:
     ``loss_fn(scorer(xs), ys, n)`` is the reference's user code unchanged.  ``scorer(xs, n)`` also
-    skips the padded documents (score 0).  The feature batch gets no gradient (it is data); an input
-    that requires one (the layer sits behind others) gets ``grad_scores (x) weight``."""
+    skips the padded documents (score 0).  While gradients are enabled the layer returns :class:`LazyScores`: a loss
+    module of this package then runs scores + loss + weight gradient as ONE kernel over the features (what
+    ``FusedLinearLoss`` does), anything else that touches the scores computes them on the spot.  The feature batch gets
+    no gradient (it is data); an input that requires one (the layer sits behind others) gets
+    ``grad_scores (x) weight``."""
 
-    def __init__(self, in_features, bias=True):
+    def __init__(self, in_features, bias=True, lazy=True):
         super().__init__()
         self.in_features = in_features
+        self.lazy = lazy
         self.weight = torch.nn.Parameter(torch.empty(1, in_features))
         self.bias = torch.nn.Parameter(torch.empty(1)) if bias else None
         torch.nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
@@ -357,9 +450,14 @@ class LinearScorer(torch.nn.Module):
             torch.nn.init.uniform_(self.bias, -bound, bound)
 
     def forward(self, xs, n=None):
-        if not (torch.is_tensor(xs) and xs.dim() == 3 and xs.is_cuda):
-            # not a (B, L, F) feature batch on the device (a value head, a gate, a 2-D input ...): the plain layer
+        if not (torch.is_tensor(xs) and xs.dim() == 3 and xs.is_cuda and xs.dtype is torch.float32
+                and xs.shape[-1] == self.in_features and not torch.is_autocast_enabled()):
+            # not an fp32 (B, L, F) feature batch on the device (a value head, a gate, a 2-D input, half precision under
+            # autocast ...): the plain layer, with nn.Linear's dtype rules and errors
             return torch.nn.functional.linear(xs, self.weight, self.bias)
+        if (self.lazy and torch.is_grad_enabled() and not xs.requires_grad and xs.is_contiguous()
+                and (self.weight.requires_grad or (self.bias is not None and self.bias.requires_grad))):
+            return LazyScores(xs, self.weight, self.bias, n)
         return _LinearScoreFunction.apply(xs, self.weight, self.bias, n)
 
 

@@ -291,6 +291,62 @@ def test_fused_module_matches_unfused_dropin():
     assert torch.allclose(fused.bias.grad, lin.bias.grad, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("kind", ["hinge", "logistic", "ndcg2"])
+def test_unchanged_user_script_reaches_the_fused_kernel(kind):
+    """`loss_fn(model(xs), ys, n).mean().backward()` with model = use_linear_scorer(nn.Linear(F, 1))
+    -- the reference's loop body unchanged (examples/01-basic-usage.py:66-75) -- runs scores, loss and weight gradient
+    as ONE pass over the features: the layer returns LazyScores, the loss module recognises them.  Same loss and
+    gradients as the plain nn.Linear composition; and anybody else who touches the scores gets real ones."""
+    from pytorchltr_amd import loss as L_
+    from pytorchltr_amd.evaluation import ndcg
+    from pytorchltr_amd.fused import LazyScores, use_linear_scorer
+    dev = _dev()
+    B, L, F = 64, 100, 136
+    s, y, n, X, W, b = synth(B, L, 31, F=F)
+    Xd, yd, nd = X.to(dev), y.to(dev), n.to(dev)
+    mk = {"hinge": L_.PairwiseHingeLoss, "logistic": lambda: L_.PairwiseLogisticLoss(0.8), "ndcg2": lambda: L_.LambdaNDCGLoss2(0.8)}[kind]
+    loss_fn = mk()
+    lin = torch.nn.Linear(F, 1).to(dev)
+    model = use_linear_scorer(torch.nn.Linear(F, 1).to(dev))
+    model.load_state_dict(lin.state_dict())
+    w = torch.rand(B, device=dev)
+    ref = loss_fn(lin(Xd), yd, nd)
+    (ref * w).sum().backward()
+    scores = model(Xd)
+    assert type(scores) is LazyScores and scores._real is None
+    assert tuple(scores.shape) == (B, L, 1) and scores.dtype is torch.float32 and scores.is_cuda and scores.requires_grad
+    out = loss_fn(scores, yd, nd)
+    assert scores._real is None                                  # the scores were never written: one fused pass
+    (out * w).sum().backward()
+    assert torch.allclose(out, ref, rtol=2e-5, atol=1e-5)
+    tol = 1e-5 * max(1.0, float(lin.weight.grad.abs().max()))     # (the bias gradient of a pairwise loss is 0 up to rounding)
+    assert torch.allclose(model.weight.grad, lin.weight.grad, rtol=1e-4, atol=tol)
+    assert torch.allclose(model.bias.grad, lin.bias.grad, rtol=1e-4, atol=tol)
+    # `.mean().backward()`, the literal user line, a second time (gradients accumulate like nn.Linear's)
+    model.zero_grad()
+    lin.zero_grad()
+    loss_fn(model(Xd), yd, nd).mean().backward()
+    loss_fn(lin(Xd), yd, nd).mean().backward()
+    assert torch.allclose(model.weight.grad, lin.weight.grad, rtol=1e-4, atol=1e-6)
+    # used by anything else, the scores are real -- and stay connected to the parameters
+    sc = model(Xd)
+    val = ndcg(sc, yd, nd, k=10)                                 # a metric of this package
+    assert sc._real is not None and torch.allclose(sc.materialize(), lin(Xd), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(val, ndcg(lin(Xd), yd, nd, k=10), rtol=1e-6)
+    sc2 = model(Xd)
+    model.zero_grad()
+    lin.zero_grad()
+    (torch.tanh(sc2).sum() + loss_fn(sc2, yd, nd).sum()).backward()    # scores used twice: computed once, both paths right
+    (torch.tanh(lin(Xd)).sum() + loss_fn(lin(Xd), yd, nd).sum()).backward()
+    assert torch.allclose(model.weight.grad, lin.weight.grad, rtol=1e-4, atol=1e-5 * float(lin.weight.grad.abs().max()))
+    with torch.no_grad():                                        # evaluation: plain scores, nothing lazy
+        assert type(model(Xd)) is torch.Tensor
+    # a converted layer fed something that is not an fp32 feature batch behaves like nn.Linear (ADVICE r4)
+    with pytest.raises(RuntimeError):
+        model(Xd.double())                                       # nn.Linear's own dtype error, not a silent fp32 cast
+    assert model(Xd[:, :, :F].reshape(B * L, F)).shape == (B * L, 1)   # 2-D input: the plain layer
+
+
 def test_example3_training_trace():
     """BASELINE.json configs[0]: examples/01-basic-usage.py on the Example3 toy data.  Linear(5,1),
     PairwiseHingeLoss, SGD lr 0.1, batch 2; published trace: test nDCG@10 0.8617 at start."""
