@@ -40,9 +40,15 @@ class RaggedQueries(_torch.utils.data.Dataset):
         csr: optional (indptr (N + 1), indices (nnz), values (nnz)): the split stored sparsely -- the reference's
             ``sparse=True`` datasets (svmrank.py:62-76,162-176); batches still come out dense and padded.
         num_features: F of a csr split (default: largest feature id + 1).
+        pad_features_to: 4 lays the rows of every batch out a multiple of four floats apart (zero columns behind the
+            real ones; the batch's ``features`` is still the (B, L, F) tensor -- a view of the padded one): feature
+            counts that are not a multiple of 4 (Example3: 5, the reference's test file: 45, MQ2007 / MQ2008: 46) then
+            take the 16-byte-vector kernels of this package (register tile, streaming scorer) instead of the scalar
+            ones; ``torch.nn.Linear`` takes the view like any other tensor.  Default 1: rows packed like the reference's.
     """
 
-    def __init__(self, features, relevance, offsets, qids=None, device="cuda", csr=None, num_features=None):
+    def __init__(self, features, relevance, offsets, qids=None, device="cuda", csr=None, num_features=None,
+                 pad_features_to=1):
         relevance = _torch.as_tensor(relevance, dtype=_torch.int64)
         offsets = _torch.as_tensor(offsets, dtype=_torch.int64).cpu()
         self.csr = None
@@ -70,6 +76,15 @@ class RaggedQueries(_torch.utils.data.Dataset):
         if offsets.dim() != 1 or offsets.numel() < 1 or int(offsets[0]) != 0 or \
                 int(offsets[-1]) != features.shape[0] or bool((offsets[1:] < offsets[:-1]).any()):
             raise ValueError("offsets must be non-decreasing, start at 0 and end at N")
+        if pad_features_to not in (1, 4):
+            raise ValueError("pad_features_to must be 1 or 4")
+        if self.num_features is None:
+            self.num_features = int(features.shape[1])
+        self._row_width = (self.num_features + pad_features_to - 1) // pad_features_to * pad_features_to
+        if csr is None and self._row_width != self.num_features:
+            wide = _torch.zeros(features.shape[0], self._row_width, dtype=_torch.float32)
+            wide[:, :self.num_features] = features
+            features = wide
         self._q = offsets.numel() - 1
         self._offsets_host = offsets
         self._counts_host = offsets[1:] - offsets[:-1]
@@ -146,7 +161,7 @@ class RaggedQueries(_torch.utils.data.Dataset):
         B = idx.numel()
         list_size, select = self.plan(idx.tolist(), list_sampler)
         dev = self.relevance.device
-        F = self.num_features
+        F = self._row_width                         # (the row width in memory: num_features, or padded to a multiple of 4)
         out_x = _torch.empty(B, list_size, F, dtype=_torch.float32, device=dev)
         out_y = _torch.empty(B, list_size, dtype=_torch.int64, device=dev)
         out_n = _torch.empty(B, dtype=_torch.int64, device=dev)
@@ -167,6 +182,8 @@ class RaggedQueries(_torch.utils.data.Dataset):
         elif B > 0:
             out_n.zero_()
         qid = self._qids_host[idx].to(dev)
+        if F != self.num_features:
+            out_x = out_x[:, :, :self.num_features]          # the reference's (B, L, F) batch, rows F4 floats apart
         return SVMRankBatch(out_x, out_y, out_n, qid, False)
 
     def collate_fn(self, list_sampler: Optional[ListSampler] = None, sort_by_length: bool = False):

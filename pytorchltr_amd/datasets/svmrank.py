@@ -86,7 +86,7 @@ def normalize_queries(xs, offsets):
     return xs
 
 
-def load_svmrank(file, normalize=False, filter_queries=False, device="cuda", n_threads=0):
+def load_svmrank(file, normalize=False, filter_queries=False, device="cuda", n_threads=0, pad_features_to=1):
     """Loads an SVMrank file as a device-resident :class:`RaggedQueries`.
 
     Args:
@@ -96,6 +96,7 @@ def load_svmrank(file, normalize=False, filter_queries=False, device="cuda", n_t
         filter_queries: drop queries without any relevant document (svmrank.py:87-96).
         device: ROCm device that will hold the split.
         n_threads: parser threads.
+        pad_features_to: 4 keeps the rows of every collated batch a multiple of four floats apart (see RaggedQueries).
     """
     from pytorchltr_amd.datasets.ragged import RaggedQueries
     xs, ys, qids = parse_svmrank_file(file, n_threads=n_threads)
@@ -113,4 +114,4 @@ def load_svmrank(file, normalize=False, filter_queries=False, device="cuda", n_t
             unique_qids = unique_qids[keep]
             offsets = _np.hstack([[0], _np.cumsum(counts[keep])]).astype(_np.int64)
     return RaggedQueries(xs.astype(_np.float32), ys.astype(_np.int64), offsets, qids=unique_qids,
-                         device=device)
+                         device=device, pad_features_to=pad_features_to)

@@ -32,7 +32,26 @@ def _resolve_loss(loss):
     return kind, float(getattr(loss, "sigma", 1.0))
 
 
+def _padded_rows(xs):
+    """A (B, L, F) view whose rows sit a multiple of four floats apart -- F4 = (F + 3) & ~3 > F, what
+    ``RaggedQueries(pad_features_to=4)`` collates (feature counts like Example3's 5, LETOR's 45 / 46: rows that are not
+    whole float4 otherwise run the scalar kernels) -- as the (B, L, F4) tensor it lives in, or None.  The hidden
+    columns meet zero weights, so any FINITE content is harmless (the collate writes zeros)."""
+    if xs.dim() != 3 or xs.dtype is not torch.float32 or not xs.is_cuda:
+        return None
+    B, L, F = xs.shape
+    F4 = (F + 3) & ~3
+    if F4 == F or B == 0 or L == 0 or xs.stride(2) != 1 or xs.stride(1) != F4 or (B > 1 and xs.stride(0) != L * F4):
+        return None
+    off = xs.storage_offset()
+    if off % 4 != 0 or xs.untyped_storage().nbytes() < 4 * (off + B * L * F4):
+        return None
+    return xs.as_strided((B, L, F4), (L * F4, F4, 1), off)
+
+
 def _prepare_features(xs):
+    """The feature batch as the kernels take it: contiguous fp32 (B, L, F') on the device -- F' = F, or the padded
+    row width of a `_padded_rows` view (the callers zero-pad the weights to match and crop the gradient)."""
     if xs.dtype is torch.float32 and xs.is_cuda and xs.dim() == 3 and xs.is_contiguous():
         return xs                                   # the common case: nothing to do
     _C.require_device(xs, "xs")
@@ -40,7 +59,17 @@ def _prepare_features(xs):
         raise ValueError("features must have shape (batch, list_size, features)")
     if xs.dtype != torch.float32:
         xs = xs.float()
-    return xs.contiguous()
+    padded = _padded_rows(xs)
+    return padded if padded is not None else xs.contiguous()
+
+
+def _pad_weight(W, Fp):
+    """W (F elements) zero-padded to the feature tensor's row width Fp."""
+    if W.numel() == Fp:
+        return W
+    out = torch.zeros(Fp, dtype=torch.float32, device=W.device)
+    out[:W.numel()] = W
+    return out
 
 
 def _flat_f32(t, count):
@@ -91,11 +120,12 @@ class _LinearLossFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xs, weight, bias, relevance, n, kind, sigma, want_scores):
         X = _prepare_features(xs)
-        B, L, F = X.shape
-        if weight.numel() != F:
-            raise ValueError("weight has %d elements, features have %d" % (weight.numel(), F))
+        B, L, F = X.shape                           # (F: the row width in memory, >= the logical feature count)
+        Fw = xs.shape[2]
+        if weight.numel() != Fw:
+            raise ValueError("weight has %d elements, features have %d" % (weight.numel(), Fw))
         dev = X.device
-        W = _flat_f32(weight, F)
+        W = _pad_weight(_flat_f32(weight, Fw), F)
         bvec = None if bias is None else _flat_f32(bias, 1)
         r, nn = _labels_and_n(relevance, n, B, L, dev)
         loss = torch.empty(B, dtype=torch.float32, device=dev)
@@ -113,6 +143,7 @@ class _LinearLossFunction(torch.autograd.Function):
                     _C.check(rc)
         ctx.save_for_backward(ws)
         ctx.dims = (B, F)
+        ctx.Fw = Fw
         ctx.w_shape = weight.shape
         ctx.has_bias = bias is not None
         if want_scores:
@@ -126,7 +157,7 @@ class _LinearLossFunction(torch.autograd.Function):
         (ws,) = ctx.saved_tensors
         B, F = ctx.dims
         go = grad_loss
-        dW = torch.empty(ctx.w_shape, dtype=torch.float32, device=ws.device)
+        dW = torch.empty(F, dtype=torch.float32, device=ws.device)
         db = torch.empty(1, dtype=torch.float32, device=ws.device)
         # `.mean().backward()` / `.sum().backward()`: autograd hands over an expanded scalar (stride 0) -- the reduction
         # reads it where it is instead of a (B,) copy being made first
@@ -138,7 +169,7 @@ class _LinearLossFunction(torch.autograd.Function):
             rc = entry(ws.data_ptr(), go.data_ptr(), B, F, dW.data_ptr(), db.data_ptr(), _C.stream_of(ws))
             if rc != 0:
                 _C.check(rc)
-        return (None, dW, db if ctx.has_bias else None, None, None, None, None, None)
+        return (None, dW[:ctx.Fw].reshape(ctx.w_shape), db if ctx.has_bias else None, None, None, None, None, None)
 
 
 _pieces_cache = {}
@@ -202,6 +233,9 @@ class FusedLinearLoss(torch.nn.Module):
         # + backward replayed, pieces vs fused: 64 x 512 x 700 LambdaNDCG2 91 vs 48 us, 100 x 1000 x 700 hinge 120 vs 78)
         return _prefer_pieces(self.kind, B, L, self.in_features)
 
+    def _prefer_pieces(self, B, L):
+        return _prefer_pieces(self.kind, B, L, self.in_features)
+
 
 def linear_loss_step(xs, weight, bias, relevance, n, loss="hinge", grad_out=None,
                      return_scores=False, return_loss_sum=False):
@@ -212,8 +246,9 @@ def linear_loss_step(xs, weight, bias, relevance, n, loss="hinge", grad_out=None
     scorer+loss kernel and the cross-query reduction (which also totals the loss)."""
     kind, sigma = _resolve_loss(loss)
     X = _prepare_features(xs)
-    B, L, F = X.shape
-    W = _flat_f32(weight, F)
+    B, L, F = X.shape                               # (F: the row width in memory -- a padded view's F4)
+    Fw = xs.shape[2]
+    W = _pad_weight(_flat_f32(weight, Fw), F)
     bvec = None if bias is None else _flat_f32(bias, 1)
     r, nn = _labels_and_n(relevance, n, B, L, X.device)
     lossv = torch.empty(B, dtype=torch.float32, device=X.device)
@@ -231,7 +266,7 @@ def linear_loss_step(xs, weight, bias, relevance, n, loss="hinge", grad_out=None
             _C.ptr(nn), B, L, F, _C.ptr(lossv), _C.ptr(scores), _C.ptr(ws), st))
         _C.check(_C.lib().ltr_linear_reduce_loss_f32(
             _C.ptr(ws), _C.ptr(go), _C.ptr(lossv), B, F, _C.ptr(dW), _C.ptr(db), _C.ptr(lsum), st))
-    out = (lossv, dW, db)
+    out = (lossv, dW[:Fw], db)
     if return_scores:
         out = out + (scores,)
     if return_loss_sum:
@@ -300,8 +335,10 @@ class _LinearScoreFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xs, weight, bias, n):
         X = _prepare_features(xs)
-        B, L, F = X.shape
-        W = weight.detach().reshape(F).float().contiguous()
+        B, L, F = X.shape                           # (F: the row width in memory -- a padded view's F4)
+        Fw = xs.shape[2]
+        W = _pad_weight(weight.detach().reshape(Fw).float().contiguous(), F)
+        ctx.Fw = Fw
         bvec = None if bias is None else bias.detach().reshape(1).float().contiguous()
         nn = None if n is None else prepare_n(n, B)
         scores = torch.empty(B, L, dtype=torch.float32, device=X.device)
@@ -338,8 +375,8 @@ class _LinearScoreFunction(torch.autograd.Function):
             gm = g
             if ctx.has_n:                                       # padded documents were not scored
                 gm = g * (torch.arange(L, device=g.device)[None, :] < nn[:, None])
-            gx = (gm.unsqueeze(-1) * Wsaved.reshape(1, 1, F)).reshape(ctx.xs_shape)
-        return (gx, out[:F].reshape(ctx.w_shape), out[F:] if ctx.has_bias else None, None)
+            gx = (gm.unsqueeze(-1) * Wsaved[:ctx.Fw].reshape(1, 1, ctx.Fw)).reshape(ctx.xs_shape)
+        return (gx, out[:ctx.Fw].reshape(ctx.w_shape), out[F:] if ctx.has_bias else None, None)
 
 
 class LazyScores(torch.Tensor):
@@ -380,7 +417,7 @@ class LazyScores(torch.Tensor):
             return None
         xs = self._xs
         B, L, F = xs.shape
-        if _prefer_pieces(kind, B, L, F):
+        if _prefer_pieces(kind, B, L, (F + 3) & ~3 if not xs.is_contiguous() else F):
             return None
         self._check_versions()
         return _LinearLossFunction.apply(xs, self._weight, self._bias, relevance, n, kind, sigma, False)
@@ -455,7 +492,7 @@ class LinearScorer(torch.nn.Module):
             # not an fp32 (B, L, F) feature batch on the device (a value head, a gate, a 2-D input, half precision under
             # autocast ...): the plain layer, with nn.Linear's dtype rules and errors
             return torch.nn.functional.linear(xs, self.weight, self.bias)
-        if (self.lazy and torch.is_grad_enabled() and not xs.requires_grad and xs.is_contiguous()
+        if (self.lazy and torch.is_grad_enabled() and not xs.requires_grad and (xs.is_contiguous() or _padded_rows(xs) is not None)
                 and (self.weight.requires_grad or (self.bias is not None and self.bias.requires_grad))):
             return LazyScores(xs, self.weight, self.bias, n)
         return _LinearScoreFunction.apply(xs, self.weight, self.bias, n)

@@ -277,3 +277,60 @@ def test_sparse_and_dense_storage_collate_to_the_same_batch():
                         num_features=4)
     out = dup.collate([0]).features.cpu()
     assert out.tolist() == [[[4.0, 0.0, 3.5, 0.0], [0.0, 0.0, 0.0, 0.0]]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F", [5, 46, 137])
+def test_rows_padded_to_whole_float4_take_the_vector_kernels(F):
+    """feature counts that are not a multiple of 4 (Example3 = BASELINE config C1: 5, the reference's
+    test file: 45, MQ2007 / MQ2008: 46) ran the scalar kernels -- no register tile.  RaggedQueries(pad_features_to=4)
+    collates batches whose rows sit F4 floats apart; `features` is still the reference's (B, L, F) tensor (a view), the
+    fused modules and the streaming scorer take the padded row width (the register tile where the shape fits) and
+    give the same losses and gradients as the packed batch, torch.nn.Linear takes the view as it is."""
+    import numpy as np
+    from oracle import ltr_oracle as O
+    from pytorchltr_amd import _C
+    from pytorchltr_amd import loss as L_
+    from pytorchltr_amd.datasets.ragged import RaggedQueries
+    from pytorchltr_amd.fused import FusedLinearLoss, linear_loss_step, use_linear_scorer
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7 + F)
+    counts = torch.randint(1, 40, (24,), generator=g)
+    offsets = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(counts, 0)])
+    N = int(offsets[-1])
+    X = torch.randn(N, F, generator=g)
+    y = torch.randint(0, 5, (N,), generator=g)
+    packed = RaggedQueries(X, y, offsets, device=dev)
+    padded = RaggedQueries(X, y, offsets, device=dev, pad_features_to=4)
+    idx = list(range(24))
+    bp, bq = packed.collate(idx), padded.collate(idx)
+    F4 = (F + 3) & ~3
+    assert tuple(bq.features.shape) == tuple(bp.features.shape) and bq.features.stride(1) == F4 and not bq.features.is_contiguous()
+    assert torch.equal(bq.features, bp.features) and torch.equal(bq.relevance, bp.relevance) and torch.equal(bq.n, bp.n)
+    B, L = bq.features.shape[:2]
+    assert _C.lib().ltr_linear_fused_plan(_C.HINGE, B, L, F4) == _C.PLAN_REGISTER_TILE
+    lin = torch.nn.Linear(F, 1).to(dev)
+    W, b = lin.weight.detach().reshape(-1), lin.bias.detach()
+    want_l, want_s, want_dW, want_db = O.linear_pairwise("hinge", bp.features.cpu().numpy(), W.cpu().numpy(), float(b[0]),
+                                                         bp.relevance.cpu().numpy(), bp.n.cpu().numpy(), np.full(B, 1.0 / B))
+    for batch in (bp, bq):
+        loss, dW, db = linear_loss_step(batch.features, W, b, batch.relevance, batch.n, loss="hinge")
+        assert dW.shape == (F,)
+        assert np.allclose(loss.cpu().numpy(), want_l, rtol=2e-5, atol=1e-5)
+        assert np.max(np.abs(dW.cpu().numpy() - want_dW)) < 2e-5 * max(1.0, float(np.max(np.abs(want_dW))))
+    # the unchanged script on the padded batch: nn.Linear, the converted layer (lazy, fused) and FusedLinearLoss agree
+    loss_fn = L_.PairwiseHingeLoss()
+    loss_fn(lin(bq.features), bq.relevance, bq.n).mean().backward()
+    model = use_linear_scorer(torch.nn.Linear(F, 1).to(dev))
+    model.load_state_dict(lin.state_dict())
+    loss_fn(model(bq.features), bq.relevance, bq.n).mean().backward()
+    fused = FusedLinearLoss(F, "hinge").to(dev)
+    fused.load_state_dict(lin.state_dict())
+    fused(bq.features, bq.relevance, bq.n).mean().backward()
+    tol = 2e-5 * max(1.0, float(lin.weight.grad.abs().max()))
+    for m in (model, fused):
+        assert m.weight.grad.shape == lin.weight.grad.shape
+        assert torch.allclose(m.weight.grad, lin.weight.grad, rtol=1e-4, atol=tol)
+        assert torch.allclose(m.bias.grad, lin.bias.grad, rtol=1e-4, atol=tol)
+    with torch.no_grad():
+        assert torch.allclose(model(bq.features), lin(bq.features), rtol=1e-5, atol=1e-5)

@@ -327,7 +327,7 @@ def test_unchanged_user_script_reaches_the_fused_kernel(kind):
     lin.zero_grad()
     loss_fn(model(Xd), yd, nd).mean().backward()
     loss_fn(lin(Xd), yd, nd).mean().backward()
-    assert torch.allclose(model.weight.grad, lin.weight.grad, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(model.weight.grad, lin.weight.grad, rtol=1e-4, atol=1e-5 * max(1.0, float(lin.weight.grad.abs().max())))
     # used by anything else, the scores are real -- and stay connected to the parameters
     sc = model(Xd)
     val = ndcg(sc, yd, nd, k=10)                                 # a metric of this package
