@@ -83,6 +83,11 @@ int ltr_max_list_len_f64(void);
 int ltr_device_status(int clear);
 /* Tests only: != 0 makes every in-launch wait of the multi-workgroup kernels give up at once. */
 void ltr_debug_force_timeout(int on);
+/* Tests only: switches of the cluster kernel (long lists on small batches; LTR_CLUSTER_MODE=<bits> in the environment
+ * does the same for a whole process).  Bit 0: treat every query's workgroups as spread over several XCDs, i.e. take the
+ * write-through protocol the kernel falls back to when the placement check of a launch fails.  Bit 1: the hinge kinds by
+ * the pair pass even where the labels are integer grades 0 .. 4 (which the kernel resolves by ranks). */
+void ltr_debug_cluster_mode(int bits);
 /* Tests only: != 0 lets the parts kernel (below) take every shape it CAN take instead of the shapes where it was
  * measured to pay (LTR_PARTS_ALL=1 in the environment does the same for a whole process); returns the old value. */
 int ltr_debug_parts_all(int on);

@@ -31,6 +31,7 @@ SIGNATURES = {
     "ltr_max_list_len_f64": (_i, []),
     "ltr_device_status": (_i, [_i]),
     "ltr_debug_force_timeout": (None, [_i]),
+    "ltr_debug_cluster_mode": (None, [_i]),
     "ltr_debug_parts_all": (_i, [_i]),
     "ltr_exchange_release": (_i, []),
     "ltr_debug_set_exchange_tag": (_i, [_vp, ctypes.c_uint32]),

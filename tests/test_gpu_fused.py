@@ -483,6 +483,34 @@ def test_cluster_kernel_long_lists_on_small_batches(kind, shape):
     assert abs(float(db.cpu()[0]) - want_db) < tol, kind
     loss2, dW2, db2 = linear_loss_step(Xd, Wd, bd, yd, nd, loss=kind, grad_out=gout.to(dev))
     assert torch.equal(loss, loss2) and torch.equal(dW, dW2) and torch.equal(db, db2)
+    # Round 5: the members of a query sit on block ids congruent mod 8 (one XCD) and hand each other plain stores
+    # through that XCD's L2 once the launch has CHECKED the placement; a cluster found spread over several XCDs
+    # re-publishes its scores write-through and keeps to the round-4 protocol.  Forced here: the same bits.
+    lib.ltr_debug_cluster_mode(1)
+    try:
+        loss3, dW3, db3 = linear_loss_step(Xd, Wd, bd, yd, nd, loss=kind, grad_out=gout.to(dev))
+    finally:
+        lib.ltr_debug_cluster_mode(0)
+    _C.device_status()
+    assert torch.equal(loss, loss3) and torch.equal(dW, dW3) and torch.equal(db, db3)
+    if kind in ("hinge", "dcg_hinge"):
+        # Round 5: integer grades 0 .. 4 -> the hinge kinds by RANKS (two binary searches per document in the list
+        # sorted by score, with the pair pass's own fp32 margin predicate) instead of the pair pass.  The per-document
+        # gradients are the same integers: for the plain hinge dW / db are bit-identical to the pair pass's, the
+        # DCG modifier scales the summed shares instead of every document (fp32 rounding), the pair sum comes from
+        # #active + sum (s - c) g.
+        lib.ltr_debug_cluster_mode(2)
+        try:
+            loss4, dW4, db4 = linear_loss_step(Xd, Wd, bd, yd, nd, loss=kind, grad_out=gout.to(dev))
+        finally:
+            lib.ltr_debug_cluster_mode(0)
+        _C.device_status()
+        assert np.allclose(loss4.cpu().numpy(), want_l, rtol=rtol, atol=1e-5)
+        assert torch.allclose(loss, loss4, rtol=2e-6, atol=1e-6)
+        if kind == "hinge":
+            assert torch.equal(dW, dW4) and torch.equal(db, db4)
+        else:
+            assert torch.allclose(dW, dW4, rtol=1e-5, atol=1e-6 * float(dW4.abs().max()))
 
 
 def test_out_of_range_list_lengths_under_the_scheduling():
