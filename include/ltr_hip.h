@@ -35,7 +35,18 @@
 extern "C" {
 #endif
 
-#define LTR_VERSION 112 /* 0.1.12 */
+/*
+ * Test and measurement hooks (ltr_debug_*): part of the default build -- the GPU test tier forces time-outs and fall-back
+ * protocols through them and bench.py measures its launch ceilings with two of them -- and LEFT OUT of the library's
+ * exports by a build with -DLTR_NO_DEBUG_HOOKS (LTR_NO_DEBUG_HOOKS=1 python -m pytorchltr_amd.build): the production build.
+ */
+#ifdef LTR_NO_DEBUG_HOOKS
+#define LTR_DEBUG_HOOK __attribute__((visibility("hidden")))
+#else
+#define LTR_DEBUG_HOOK
+#endif
+
+#define LTR_VERSION 113 /* 0.1.13 */
 
 /* Loss kinds: one per class exported by pytorchltr/loss/__init__.py:1-7. */
 enum ltr_loss_kind {
@@ -82,15 +93,15 @@ int ltr_max_list_len_f64(void);
  */
 int ltr_device_status(int clear);
 /* Tests only: != 0 makes every in-launch wait of the multi-workgroup kernels give up at once. */
-void ltr_debug_force_timeout(int on);
+LTR_DEBUG_HOOK void ltr_debug_force_timeout(int on);
 /* Tests only: switches of the cluster kernel (long lists on small batches; LTR_CLUSTER_MODE=<bits> in the environment
  * does the same for a whole process).  Bit 0: treat every query's workgroups as spread over several XCDs, i.e. take the
  * write-through protocol the kernel falls back to when the placement check of a launch fails.  Bit 1: the hinge kinds by
  * the pair pass even where the labels are integer grades 0 .. 4 (which the kernel resolves by ranks). */
-void ltr_debug_cluster_mode(int bits);
+LTR_DEBUG_HOOK void ltr_debug_cluster_mode(int bits);
 /* Tests only: != 0 lets the parts kernel (below) take every shape it CAN take instead of the shapes where it was
  * measured to pay (LTR_PARTS_ALL=1 in the environment does the same for a whole process); returns the old value. */
-int ltr_debug_parts_all(int on);
+LTR_DEBUG_HOOK int ltr_debug_parts_all(int on);
 /*
  * Exchange areas.  The fused-scorer kernels that spread a query over several workgroups (the parts kernel
  * behind ltr_linear_partials_f32 / ltr_linear_pairwise_f32 / ltr_linear_step_f32 for long lists and wide rows)
@@ -107,18 +118,18 @@ int ltr_debug_parts_all(int on);
 int ltr_exchange_release(void);
 /* Tests only: the granule tag the NEXT launch on `stream`'s exchange area uses (tags run 1 .. 2^32 - 1 and
  * start over; the launch that uses the last one zeroes the granule buffers on its way out). */
-int ltr_debug_set_exchange_tag(void *stream, unsigned tag);
+LTR_DEBUG_HOOK int ltr_debug_set_exchange_tag(void *stream, unsigned tag);
 /* Measurement aid (bench.py `roofline.launch_ceiling`): the launch geometry of the register-tile kernel --
  * one 512-thread workgroup per query, 16-byte buffer loads over the query's n[b] * F real floats, all in
  * flight at once -- with no computation behind the loads: every wave stores one dword to out
  * (B * 8 floats).  Shapes with L * F / 4 <= 19 * 512 vectors per query. */
-int ltr_debug_stream_probe_f32(const float *X, const int64_t *n, int B, int L, int F, float *out, void *stream);
+LTR_DEBUG_HOOK int ltr_debug_stream_probe_f32(const float *X, const int64_t *n, int B, int L, int F, float *out, void *stream);
 /* Tests / measurements only: which kernel layout ltr_mlp_pairwise_f32 takes where both apply.
  * 0 = automatic (the 4-wave tile kernel of csrc/ltr_mlp2.inc for batches of at least two queries per
  * CU-slot and for lists over 128 documents, else the 8-wave kernel of csrc/ltr_mlp.inc), 1 = the
  * 8-wave kernel wherever it applies, 2 = the tile kernel wherever it applies.
  * LTR_MLP_LAYOUT in the environment sets the initial value. */
-void ltr_debug_mlp_layout(int layout);
+LTR_DEBUG_HOOK void ltr_debug_mlp_layout(int layout);
 
 /*
  * Seven pairwise losses, forward + analytic gradient in ONE pass.
@@ -413,10 +424,10 @@ int ltr_linear_sgd_steps_f32(int kind, float sigma, int K, const float *const *X
 /* 1 when ltr_linear_sgd_steps_f32 takes this shape on the persistent kernel, 0 when it runs K per-step calls. */
 int ltr_linear_sgd_steps_plan(int kind, int B, int L, int F);
 /* Tests only: != 0 makes every wait of the persistent kernel give up at once. */
-void ltr_debug_steps_force_timeout(int on);
+LTR_DEBUG_HOOK void ltr_debug_steps_force_timeout(int on);
 /* Tuning only: a device buffer of K * B * 8 int64 that later ltr_linear_sgd_steps_f32 launches fill with 100 MHz
  * wall-clock stamps per step and workgroup (scripts/dev/trace_steps.py), or NULL to stop. */
-void ltr_debug_steps_trace(long long *buffer);
+LTR_DEBUG_HOOK void ltr_debug_steps_trace(long long *buffer);
 /* Mailbox all-reduce: the < 3 KB gradient bucket of a data-parallel step summed over the ranks of ONE node by a
  * single small kernel per rank instead of a collective library (one process per GPU; no counterpart in the
  * reference, which is single-process).  Every rank owns a mailbox of 8-byte {tag, value} granules in fine-grained
@@ -435,14 +446,17 @@ void ltr_debug_steps_trace(long long *buffer);
 int ltr_mailbox_create(int rank, int world, int count_max, void **handle, void *ipc_handle_out /* 64 bytes */);
 int ltr_mailbox_connect(void *handle, const void *all_ipc_handles /* world x 64 bytes, rank order */);
 int ltr_mailbox_destroy(void *handle);
+/* The time budget of the mailbox's polls for the whole process (milliseconds, > 0; default 120 000 or LTR_MAILBOX_TIMEOUT_MS);
+ * returns the previous value.  MailboxOverlap's set-up self-check runs under a short budget and restores it. */
+long long ltr_mailbox_set_timeout_ms(long long timeout_ms);
 int ltr_mailbox_allreduce(const void *sendbuf, void *recvbuf, size_t count, int datatype, int op, void *comm,
                           void *stream);
 /* Tests only: timeout_ms > 0 sets the time budget of every later mailbox all-reduce of the process; tag >= 0 makes
  * `tag` the number of all-reduces this mailbox has done (the wrap 0xFFFFFFFF -> 2: every rank sets the same). */
-int ltr_debug_mailbox_state(void *handle, long long timeout_ms, long long tag);
+LTR_DEBUG_HOOK int ltr_debug_mailbox_state(void *handle, long long timeout_ms, long long tag);
 /* Tests only: an ltr_allreduce_fn that adds `comm` -- a device pointer to `count` floats, "the other rank's
  * bucket" -- to the buffer on `stream` (ncclFloat32 / ncclSum only). */
-int ltr_debug_fake_allreduce(const void *sendbuf, void *recvbuf, size_t count, int datatype, int op, void *comm,
+LTR_DEBUG_HOOK int ltr_debug_fake_allreduce(const void *sendbuf, void *recvbuf, size_t count, int datatype, int op, void *comm,
                              void *stream);
 
 /* --- fused ReLU-MLP scorer + loss + backward --------------------
@@ -473,7 +487,7 @@ int ltr_mlp_pairwise_f32(int kind, float sigma, const float *X, const float *W1,
  * back, the same barriers and MFMA streams (80 forward + 88 backward MFMAs per fill and wave), the same assignment of queries to
  * workgroups -- with no labels, per-document layer-2/3 work, parking, pair pass or partial vectors: every wave stores one dword to
  * out (2 * #CUs * 4 floats at most).  F = 136 and L <= 128 only (the named batch); the numbers mean nothing. */
-int ltr_debug_mlp_probe_f32(const float *X, const float *W1, const float *b1, const float *W2, const float *b2,
+LTR_DEBUG_HOOK int ltr_debug_mlp_probe_f32(const float *X, const float *W1, const float *b1, const float *W2, const float *b2,
                             const float *W3, const float *b3, const int64_t *n, int B, int L, int F, int H1, int H2,
                             float *out, void *stream);
 

@@ -83,6 +83,7 @@ SIGNATURES = {
     "ltr_mailbox_destroy": (_i, [_vp]),
     "ltr_mailbox_allreduce": (_i, [_vp, _vp, _sz, _i, _i, _vp, _vp]),
     "ltr_debug_mailbox_state": (_i, [_vp, ctypes.c_longlong, ctypes.c_longlong]),
+    "ltr_mailbox_set_timeout_ms": (ctypes.c_longlong, [ctypes.c_longlong]),
     "ltr_linear_pairwise_f32": (_i, [_i, _f, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i,
                                      _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ltr_linear_partials_f32": (_i, [_i, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i,
@@ -120,6 +121,8 @@ def lib():
                 "There is no CPU fallback." % LIB_PATH)
         handle = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
+            if name.startswith("ltr_debug_") and not hasattr(handle, name):
+                continue                     # a production build (-DLTR_NO_DEBUG_HOOKS) leaves the test hooks out
             fn = getattr(handle, name)       # AttributeError if the symbol is missing
             fn.restype = restype
             fn.argtypes = argtypes

@@ -52,6 +52,8 @@ def build_extension(force=False, verbose=False, extra_flags=(), lib_path=None):
     os.makedirs(obj_dir, exist_ok=True)
     common = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
               "-pthread", "-Wall", "-Wno-unused-function", "-I", os.path.join(_ROOT, "include"), "-I", CSRC] + list(extra_flags)
+    if os.environ.get("LTR_NO_DEBUG_HOOKS") == "1":      # production build: the ltr_debug_* test hooks are not exported
+        common.append("-DLTR_NO_DEBUG_HOOKS")
     jobs = []
     for src in SOURCES:
         obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")

@@ -403,7 +403,7 @@ class MailboxOverlap:
         budget_ms = int(os.environ.get("LTR_MAILBOX_CHECK_TIMEOUT_MS", "5000"))
         default_ms = int(os.environ.get("LTR_MAILBOX_TIMEOUT_MS", "0")) or 120000
         try:
-            self.lib.ltr_debug_mailbox_state(None, budget_ms, -1)
+            self.lib.ltr_mailbox_set_timeout_ms(budget_ms)
             rank = dist.get_rank(self.group) if dist.is_initialized() else 0
             for rep in range(3):
                 v = (torch.arange(self.F + 2, dtype=torch.float32, device=self.device) + 1.0 + rep) * float(rank + 1) * 0.37
@@ -424,7 +424,7 @@ class MailboxOverlap:
             self._check_note = repr(exc)
             ok = False
         finally:
-            self.lib.ltr_debug_mailbox_state(None, default_ms, -1)
+            self.lib.ltr_mailbox_set_timeout_ms(default_ms)
             if not ok:
                 try:
                     torch.cuda.synchronize(self.device)

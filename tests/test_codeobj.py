@@ -81,4 +81,4 @@ def test_no_fused_scorer_kernel_outside_the_known_exceptions_spills():
 def test_spilling_kernel_count_only_goes_down():
     recs = _records()
     spilling = [r for r in recs if r.get("vgpr_spill_count", 0) > 0]
-    assert len(spilling) <= 30, sorted((r.get("demangled", r["name"])[:70], r["vgpr_spill_count"]) for r in spilling)
+    assert len(spilling) <= 29, sorted((r.get("demangled", r["name"])[:70], r["vgpr_spill_count"]) for r in spilling)
