@@ -538,3 +538,75 @@ def test_out_of_range_list_lengths_under_the_scheduling():
     l1, g1 = pairwise_loss_and_grad(s2.to(dev), y2.to(dev), wild2.to(dev), _C.NDCG2)
     l2, g2 = pairwise_loss_and_grad(s2.to(dev), y2.to(dev), wild2.clamp(0, L).to(dev), _C.NDCG2)
     assert torch.equal(l1, l2) and torch.equal(g1, g2)
+
+
+def _sorted_runs_cases(count, seed):
+    import random
+    rnd = random.Random(seed)
+    out = []
+    for _ in range(count):
+        F = rnd.choice([64, 136, 220])
+        L = rnd.choice([257, 300, 512, 600, 777, 1000, 1024])
+        B = rnd.choice([1, 3, 8, 9, 31, 33, 48])
+        out.append((B, L, F, rnd.choice(["hinge", "dcg_hinge"]), rnd.choice(["ties", "margin", "mixed_labels", "int32", "plain"]),
+                    rnd.randrange(1 << 20)))
+    return out
+
+
+@pytest.mark.parametrize("case", _sorted_runs_cases(30, 20260930), ids=lambda c: "%dx%dx%d-%s-%s-%d" % c)
+def test_hinge_by_sorted_runs_against_the_pair_pass(case):
+    """Round 5: seeded stress of the sorted-runs path of the cluster kernel's 8-sweep members against its own pair pass
+    (`ltr_debug_cluster_mode(2)`) and the oracle -- scores with many exact ties (features and weights on a coarse grid),
+    score differences EXACTLY at the margin and one ulp to either side of it, batches in which some queries carry a
+    grade outside 0..4 or a negative one (those queries take the pair pass, the others the runs: every member of a query
+    decides alike), int32 labels.  The per-document gradients are integers either way: for the plain hinge dW and db
+    must be bit-identical between the two paths; losses to fp32 rounding."""
+    from pytorchltr_amd import _C
+    from pytorchltr_amd.fused import linear_loss_step
+    B, L, F, kind, flavour, seed = case
+    lib = _C.lib()
+    if lib.ltr_linear_fused_plan(getattr(_C, kind.upper()), B, L, F) != _C.PLAN_CLUSTER:
+        pytest.skip("not a cluster shape")
+    dev = _dev()
+    g = torch.Generator().manual_seed(seed)
+    s_, y, n, X, W, b = synth(B, L, seed, F=F)
+    if flavour == "ties":
+        X = torch.round(X * 2) / 2
+        W = torch.round(W * 8 * F ** 0.5) / 8                    # sums of a few multiples of 1/16: plenty of equal scores
+        b = torch.zeros(1)
+    elif flavour == "margin":
+        # column 0 is the score (W = e_0, bias 0): exact differences of 1 and 1 +- one ulp between neighbours
+        W = torch.zeros(F); W[0] = 1.0; b = torch.zeros(1)
+        base = torch.randn(B, L, generator=g).float()
+        base[:, 1::3] = base[:, 0::3][:, :base[:, 1::3].shape[1]] - 1.0
+        up = torch.nextafter(base[:, 0::3] - 1.0, torch.full_like(base[:, 0::3], 10.0))
+        base[:, 2::3] = up[:, :base[:, 2::3].shape[1]]
+        X = X.clone(); X[:, :, 0] = base
+    elif flavour == "mixed_labels":
+        y = y.clone()
+        y[::3, 5] = 7                                              # a grade above 4 in every third query
+        if B > 1:
+            y[1::3, 2] = -1                                        # a negative one
+    n[0] = L
+    if B > 2:
+        n[1], n[2] = 1, 0
+    ydev = y.to(dev).to(torch.int32) if flavour == "int32" else y.to(dev)
+    Xd, Wd, bd, nd = X.to(dev), W.to(dev), b.to(dev), n.to(dev)
+    loss, dW, db = linear_loss_step(Xd, Wd, bd, ydev, nd, loss=kind)
+    lib.ltr_debug_cluster_mode(2)
+    try:
+        loss_p, dW_p, db_p = linear_loss_step(Xd, Wd, bd, ydev, nd, loss=kind)
+    finally:
+        lib.ltr_debug_cluster_mode(0)
+    _C.device_status()
+    assert torch.isfinite(loss).all()
+    assert torch.allclose(loss, loss_p, rtol=3e-6, atol=2e-5)
+    if kind == "hinge":
+        assert torch.equal(dW, dW_p) and torch.equal(db, db_p)
+    else:
+        assert torch.allclose(dW, dW_p, rtol=2e-5, atol=2e-6 * float(dW_p.abs().max() + 1e-30))
+    if flavour not in ("margin", "ties"):        # (at exact ties / margins the fp64 oracle's scores decide some pairs the other way)
+        want_l, _, want_dW, want_db = O.linear_pairwise(kind, X.numpy(), W.numpy(), float(b[0]), y.numpy(), n.numpy(), np.full(B, 1.0 / B))
+        assert np.allclose(loss.cpu().numpy(), want_l, rtol=5e-4, atol=1e-5)
+        tol = 4e-4 * max(1.0, float(np.max(np.abs(want_dW))))
+        assert np.max(np.abs(dW.cpu().numpy() - want_dW)) < tol
