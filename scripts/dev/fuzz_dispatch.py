@@ -16,7 +16,7 @@ t_end = time.time() + (float(sys.argv[2]) if len(sys.argv) > 2 else 120)
 cases = bad = 0
 plans = {}
 while time.time() < t_end:
-    regime = rnd.choice(["wide", "wide_short", "rt1024", "ndcg_cluster", "ndcg_parts"])
+    regime = rnd.choice(["wide", "wide_short", "rt1024", "ndcg_cluster", "ndcg_parts", "hinge_cluster", "hinge_cluster"])
     kind = rnd.choice(KINDS)
     if regime == "wide":
         B, L, F = rnd.choice([65, 130, 200, 257, 300, 384, 520]), rnd.choice([300, 400, 512, 640, 768, 1000]), rnd.choice([448, 512, 576, 640, 700])
@@ -24,6 +24,9 @@ while time.time() < t_end:
         B, L, F = rnd.choice([512, 600, 1024]), rnd.choice([100, 128, 200, 256]), rnd.choice([640, 700, 764])
     elif regime == "rt1024":
         B, L, F = rnd.choice([3, 64, 257, 600]), rnd.choice([129, 150, 172, 181, 200, 216, 217, 255, 256]), rnd.choice([100, 120, 136, 160, 220, 300])
+    elif regime == "hinge_cluster":      # round 5: the hinge kinds by sorted runs (light members, also on large batches of the longest lists)
+        kind = rnd.choice(["hinge", "dcg_hinge"])
+        B, L, F = rnd.choice([1, 7, 33, 64, 100, 200, 256, 300, 384]), rnd.choice([257, 300, 512, 700, 999, 1000, 1001, 1024]), rnd.choice([16, 64, 136, 220, 384, 520, 700])
     elif regime == "ndcg_cluster":
         kind = rnd.choice(["ndcg1", "ndcg2"])
         B, L, F = rnd.choice([5, 33, 64, 100, 200, 256, 380]), rnd.choice([257, 300, 512, 700, 1000, 1024]), rnd.choice([16, 64, 136, 220, 384])

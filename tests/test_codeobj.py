@@ -29,8 +29,8 @@ def _records():
 BASELINE_KERNELS = [
     "linear_regtile2_kernel<0, 9, 34, 512>",        # C2  1024 x 128 x 136 hinge (the headline)
     "linear_regtile2_kernel<6, 19, 34, 256>",       # C3  LambdaNDCG2
-    "linear_cluster_kernel<1, 512, 12>",            # C4  256 x 1000 x 220 DCG-hinge
-    "linear_cluster_kernel<1, 512, 8>",             # C4 shard of 8 GPUs (32 queries)
+    "linear_cluster_kernel<1, 512, 8>",             # C4  256 x 1000 x 220 DCG-hinge (integer labels: sorted runs) and its shard of 8 GPUs (32 queries)
+    "linear_cluster_kernel<1, 512, 12>",            # C4 on float labels (the pair pass)
     "linear_parts_kernel<0, 16, 3, 2, 0>",          # C5  512 x 512 x 700 hinge
     "linear_cluster_kernel<0, 1024, 19>",           # C5 shard of 8 GPUs (64 queries)
     "linear_reduce_kernel(",                        # the cross-query reduction (+ SGD update) of every fused step
