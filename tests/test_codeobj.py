@@ -31,7 +31,7 @@ BASELINE_KERNELS = [
     "linear_regtile2_kernel<6, 19, 34, 256>",       # C3  LambdaNDCG2
     "linear_cluster_kernel<1, 512, 8>",             # C4  256 x 1000 x 220 DCG-hinge (integer labels: sorted runs) and its shard of 8 GPUs (32 queries)
     "linear_cluster_kernel<1, 512, 12>",            # C4 on float labels (the pair pass)
-    "linear_parts_kernel<0, 16, 3, 2, 0>",          # C5  512 x 512 x 700 hinge
+    "linear_parts_kernel<0, 16, 3, 2, 0, false>",   # C5  512 x 512 x 700 hinge
     "linear_cluster_kernel<0, 1024, 19>",           # C5 shard of 8 GPUs (64 queries)
     "linear_reduce_kernel(",                        # the cross-query reduction (+ SGD update) of every fused step
     "sgd_update_kernel(",
@@ -62,8 +62,8 @@ def test_no_fused_scorer_kernel_outside_the_known_exceptions_spills():
     the register-resident tile (its callee-saved registers are stored around it by the ABI), and the LambdaNDCG
     instantiations of the older register-tile / cluster layouts at their largest tile."""
     recs = _records()
-    known = ("linear_parts_kernel<0, 40, 1, 2, 1>", "linear_parts_kernel<0, 20, 2, 2, 1>", "linear_parts_kernel<0, 14, 3, 2, 1>",
-             "linear_parts_kernel<1, 40, 1, 2, 1>", "linear_parts_kernel<1, 20, 2, 2, 1>", "linear_parts_kernel<1, 14, 3, 2, 1>",
+    known = ("linear_parts_kernel<0, 40, 1, 2, 1, false>", "linear_parts_kernel<0, 20, 2, 2, 1, false>", "linear_parts_kernel<0, 14, 3, 2, 1, false>",
+             "linear_parts_kernel<1, 40, 1, 2, 1, false>", "linear_parts_kernel<1, 20, 2, 2, 1, false>", "linear_parts_kernel<1, 14, 3, 2, 1, false>",
              "linear_regtile_kernel<", "linear_regtile2_kernel<5, 24,", "linear_regtile2_kernel<6, 24,",       # (the NDCG kinds on 24 sweeps: 4-12 VGPRs, and faster than the two-pass kernel)
             
              "linear_cluster_kernel<5,", "linear_cluster_kernel<6,", "linear_cluster_kernel<2, 512, 12>",

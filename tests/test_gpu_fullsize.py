@@ -123,7 +123,13 @@ def test_c5_full_size_general_kernel_all_rows():
                                    ("ndcg1", 150, 1000, 512), ("ndcg2", 90, 768, 640), ("ndcg2", 300, 400, 700),
                                    ("ndcg2", 128, 1000, 136), ("ndcg1", 100, 700, 220), ("ndcg2", 100, 400, 64),
                                    # short lists on wide rows (Yahoo-shaped: the general kernel reads the features twice)
-                                   ("hinge", 600, 128, 700), ("logistic", 520, 256, 640), ("arp1", 300, 100, 512)])
+                                   ("hinge", 600, 128, 700), ("logistic", 520, 256, 640), ("arp1", 300, 100, 512),
+                                   # round 5: the LDS landing buffer (logistic / LambdaARP at two workgroups per CU: the next
+                                   # part's first sweeps by LDS-DMA) -- persistent workgroups with many parts each, a DIRECT
+                                   # launch (one part per workgroup: the sweeps still go through LDS), rows of one / two /
+                                   # three column vectors per lane, a part of fewer rows than the landing buffer holds
+                                   ("arp2", 512, 512, 700), ("logistic", 100, 512, 700), ("arp1", 700, 400, 256),
+                                   ("logistic", 640, 300, 512), ("arp2", 900, 70, 700)])
 def test_parts_kernel_shapes_all_rows(shape):
     """Long lists (beyond the symmetric pass) and wide rows, every kind, all rows."""
     from pytorchltr_amd import _C
