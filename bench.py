@@ -180,9 +180,10 @@ def time_launches(fn, nbuf, rounds=4, replays=10):
     return start.elapsed_time(end) * 1e3 / (count * replays), replay is not None
 
 
-def time_region(fn, steps, barrier, repeats=5, reduce_max=None):
+def time_region(fn, steps, barrier, repeats=5, reduce_max=None, finish=None):
     """`repeats` timed regions of `steps` calls of fn(i), each bracketed by barrier + synchronize;
-    returns the list of elapsed seconds (max over ranks when reduce_max is given)."""
+    returns the list of elapsed seconds (max over ranks when reduce_max is given).  finish(): work the steps left
+    pending (the lazy step's last update), INSIDE the timed region."""
     out = []
     k = 0
     for _ in range(repeats):
@@ -192,6 +193,8 @@ def time_region(fn, steps, barrier, repeats=5, reduce_max=None):
         for _i in range(steps):
             fn(k)
             k += 1
+        if finish is not None:
+            finish()
         torch.cuda.synchronize()
         barrier()
         dt = time.perf_counter() - t0
@@ -239,6 +242,7 @@ class FusedStep:
         # of the GLOBAL mean loss -- what `.mean().backward()` gives on the unsharded batch
         self.go = torch.full((B,), 1.0 / (B * n_gpus), device=dev)
         self.plan = PLAN_NAMES.get(self.lib.ltr_linear_fused_plan(self.kind_id, B, L, F), "?")
+        self.pending = 0
 
     @staticmethod
     def _stream():
@@ -273,9 +277,61 @@ class FusedStep:
             self.F, float(lr), self.lossv.data_ptr(), self.flat.data_ptr(), self.part.data_ptr(), self.ws_bytes,
             None, self._stream()))
 
+    def lazy_step(self, batch, lr=SGD_LR):
+        """The same step, the update applied lazily (ltr_linear_sgd_lazy_step_f32): ONE launch -- this batch's per-query
+        gradient rows, and the previous batch's reduction + W -= lr * dW inside it; lazy_flush() applies the last one."""
+        self._C.check(self.lib.ltr_linear_sgd_lazy_step_f32(
+            self.kind_id, 1.0, batch["X"].data_ptr(), self.W.data_ptr(), self.bias.data_ptr(),
+            batch["rel"].data_ptr(), self._C.LABEL_I64, batch["n"].data_ptr(), self.B, self.L, self.F, float(lr),
+            self.lossv.data_ptr(), self.flat.data_ptr(), self.part.data_ptr(), self.ws_bytes, self.pending, self._stream()))
+        self.pending = self.B
+
+    def lazy_flush(self, lr=SGD_LR):
+        self._C.check(self.lib.ltr_linear_sgd_flush_f32(
+            self.W.data_ptr(), self.bias.data_ptr(), self.pending, self.F, float(lr), self.lossv.data_ptr(),
+            self.flat.data_ptr(), self.part.data_ptr(), self._stream()))
+        self.pending = 0
+
     def step_two_calls(self, batch, accumulate=False, flat=None):
         self.kernel(batch)
         self.reduce(accumulate, flat)
+
+
+def lazy_kernel_us(fs, batches, nbuf, count=400):
+    """Average duration (us) of the lazy step's launch itself: an event pair per launch, recorded by the command processor
+    at the kernel's begin and end (include/ltr_hip.h: ltr_debug_kernel_events); None without the hook / the HIP runtime."""
+    import ctypes
+    lib = fs.lib
+    if not hasattr(lib, "ltr_debug_kernel_events"):
+        return None
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+    except OSError:
+        return None
+    evs = []
+    for _ in range(2 * count):
+        e = ctypes.c_void_p()
+        if hip.hipEventCreate(ctypes.byref(e)) != 0:
+            return None
+        evs.append(e)
+    for i in range(2 * nbuf):
+        fs.lazy_step(batches[i % nbuf])
+    for i in range(count):
+        lib.ltr_debug_kernel_events(evs[2 * i], evs[2 * i + 1])
+        fs.lazy_step(batches[i % nbuf])
+    fs.lazy_flush()
+    torch.cuda.synchronize()
+    per = []
+    for i in range(count):
+        ms = ctypes.c_float()
+        if hip.hipEventElapsedTime(ctypes.byref(ms), evs[2 * i], evs[2 * i + 1]) == 0:
+            per.append(ms.value * 1e3)
+    for e in evs:
+        hip.hipEventDestroy(e)
+    if not per:
+        return None
+    per.sort()
+    return {"avg": sum(per) / len(per), "median": per[len(per) // 2], "min": per[0], "count": len(per)}
 
 
 PMC_STALE = set()     # workloads whose committed counters belong to older kernel sources
@@ -693,7 +749,17 @@ def main():
     # ---- the timed step: fused scorer + loss forward, backward to dW/db, eager, through the C ABI ----
     red = None
     allreduce_impl = None
-    if dist is None:
+    finish = None
+    lazy_headline = dist is None and os.environ.get("LTR_BENCH_EAGER_STEP") != "1" and hasattr(_C.lib(), "ltr_linear_sgd_lazy_step_f32")
+    if lazy_headline:
+        # one C-ABI call and ONE launch per step: the update of step k rides in step k + 1's launch (bit-identical weights:
+        # tests/test_gpu_step.py); every timed region ends with the flush of its last update
+        def step(i):
+            fs.lazy_step(batches[i % nbuf])
+
+        def finish():
+            fs.lazy_flush()
+    elif dist is None:
         def step(i):
             fs.sgd_step(batches[i % nbuf])
     elif accum == 1:
@@ -767,6 +833,8 @@ def main():
 
     for i in range(max(args.warmup, 2 * nbuf)):
         step(i)
+    if finish is not None:
+        finish()
     torch.cuda.synchronize()
     # enough steps for a >= 50 ms timed region (aim at 60), a multiple of the all-reduce period
     est_steps = 25 * accum
@@ -776,6 +844,8 @@ def main():
         t0 = time.perf_counter()
         for i in range(est_steps):
             step(i)
+        if finish is not None:
+            finish()
         torch.cuda.synchronize()
         ests.append((time.perf_counter() - t0) / est_steps)
     est = min(ests)
@@ -785,7 +855,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         steps_timed = int(t.item())
     steps_timed = ((steps_timed + accum - 1) // accum) * accum
-    regions = time_region(step, steps_timed, barrier, repeats=5, reduce_max=reduce_max)
+    regions = time_region(step, steps_timed, barrier, repeats=5, reduce_max=reduce_max, finish=finish)
     if red is not None:
         red.flush()
         if hasattr(red, "close"):
@@ -820,6 +890,17 @@ def main():
         noupd = {"queries_per_s": n_gpus * B * max(1, steps_timed // 2) / median(r0),
                  "ms_per_step": median(r0) / max(1, steps_timed // 2) * 1e3,
                  "what": "ltr_linear_step_f32: the same two launches, W left alone (rounds 1-3 reported this)"}
+
+    # the step as rounds 4-5 timed it: two launches per step (ltr_linear_sgd_step_f32: kernel, then reduction + update)
+    eager2 = None
+    if lazy_headline:
+        for i in range(2 * nbuf):
+            fs.sgd_step(batches[i % nbuf])
+        r1 = time_region(lambda i: fs.sgd_step(batches[i % nbuf]), max(1, steps_timed // 2), barrier, repeats=3, reduce_max=reduce_max)
+        eager2 = {"queries_per_s": n_gpus * B * max(1, steps_timed // 2) / median(r1),
+                  "ms_per_step": median(r1) / max(1, steps_timed // 2) * 1e3,
+                  "what": "ltr_linear_sgd_step_f32: the same steps as two launches each (kernel; reduction + update) -- the "
+                          "headline of rounds 4-5; same weights bit for bit"}
 
     # the persistent multi-batch launch of SURVEY.md 8(d): the SAME steps (same rotating batches, same SGD update) as K-step
     # launches of ltr_linear_sgd_steps_f32 -- one workgroup per query position resident over the batches, the reduction and
@@ -864,6 +945,8 @@ def main():
         extra = {"timed_regions_s": regions, "steps_per_region": steps_timed}
         if noupd is not None:
             extra["step_without_weight_update"] = noupd
+        if eager2 is not None:
+            extra["two_launch_step"] = eager2
         if persistent is not None:
             extra["persistent_multi_batch"] = persistent
         _ = pmc_record(args.workload)
@@ -896,6 +979,22 @@ def main():
                                "note": "SURVEY.md 8(d) bytes (padded rows counted although never read)"},
             "valu_issue_frac": valu_frac(pmc.get("valu_insts_per_launch"), k_us),
         }
+        if lazy_headline:
+            # the launch of the timed step is this kernel WITH the previous step's reduction and update in it: its own duration,
+            # live, from event pairs the command processor records at the kernel's begin and end (ltr_debug_kernel_events ->
+            # hipExtLaunchKernelGGL), over back-to-back lazy steps on the rotating batches
+            lz = lazy_kernel_us(fs, batches, nbuf)
+            if lz is not None:
+                roofline["plain_kernel"] = {"kernel_us_avg": k_us, "frac": roofline["frac"], "achieved": roofline["achieved"],
+                                            "what": "the same kernel launched through ltr_linear_partials_f32 (no pending update in the "
+                                                    "launch): what rounds 1-5 reported here; " + roofline["timing"]}
+                roofline["kernel"] = "%s<%s> (via ltr_linear_sgd_lazy_step_f32: + the previous step's reduction and update)" % (fs.plan, kind)
+                roofline["kernel_us_avg"] = lz["avg"]
+                roofline["timing"] = ("start / stop events recorded at the kernel's begin and end (hipExtLaunchKernelGGL) of %d back-to-back "
+                                      "eager lazy steps over %d rotating batches" % (lz["count"], nbuf))
+                roofline["kernel_us_median_min"] = [lz["median"], lz["min"]]
+                roofline["achieved"] = moved / (lz["avg"] * 1e-6) / 1e9
+                roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
         # the same bytes against the whole STEP (kernel + reduction launch + update): what HBM delivers per step
         step_s = elapsed / steps_timed
         roofline["step_level"] = {"us_per_step": step_s * 1e6, "frac": moved / step_s / 1e9 / HBM_PEAK_GBS,
@@ -956,11 +1055,17 @@ def main():
                                                                 " (full lists)" if args.full_lists else ""),
                        "global_batch": n_gpus * B, "list_len": L, "features": F, "loss": kind,
                        "mode": "eager", "parallelism": "dp%d" % n_gpus,
-                       "step": ("synchronous SGD step in one C-ABI call (ltr_linear_sgd_step_f32): fused scorer + loss "
+                       "step": (("synchronous SGD step in one C-ABI call AND ONE LAUNCH (ltr_linear_sgd_lazy_step_f32): fused scorer + "
+                                 "loss kernel whose first workgroups sum the PREVIOUS step's per-query gradient rows into [dW | db | "
+                                 "loss_sum], apply W -= lr * dW (lr %g) and hand the new weights to every workgroup before the dot "
+                                 "products; each timed region ends with ltr_linear_sgd_flush_f32 (the last step's update): as many "
+                                 "updates as steps, weights bit-identical to the two-launch step (extra.two_launch_step) -- "
+                                 "examples/01-basic-usage.py:66-75" % SGD_LR) if lazy_headline else
+                                ("synchronous SGD step in one C-ABI call (ltr_linear_sgd_step_f32): fused scorer + loss "
                                 "kernel, cross-query reduction into [dW | db | loss_sum]%s, W -= lr * dW (lr %g) -- "
                                 "examples/01-basic-usage.py:66-75" % (
                                     ", the step's gradient all-reduce" if dist is not None else
-                                    " with the update riding in it", SGD_LR)) if accum == 1 else
+                                    " with the update riding in it", SGD_LR))) if accum == 1 else
                                "gradient accumulation (no weight update in the timed region)",
                        "batches_in_rotation": nbuf, "steps_timed": steps_timed, "repeats": 5,
                        "statistic": "median of 5 timed regions",

@@ -124,6 +124,10 @@ LTR_DEBUG_HOOK int ltr_debug_set_exchange_tag(void *stream, unsigned tag);
  * flight at once -- with no computation behind the loads: every wave stores one dword to out
  * (B * 8 floats).  Shapes with L * F / 4 <= 19 * 512 vectors per query. */
 LTR_DEBUG_HOOK int ltr_debug_stream_probe_f32(const float *X, const int64_t *n, int B, int L, int F, float *out, void *stream);
+/* Measurement aid (bench.py `roofline` of the lazy step): the NEXT launch of the 512-thread register-tile kernel made by the
+ * calling thread records the HIP events `start` right before and `stop` right behind the kernel (hipExtLaunchKernelGGL): the
+ * kernel's own duration on its stream, as a profiler's kernel trace sees it. */
+LTR_DEBUG_HOOK int ltr_debug_kernel_events(void *start /* hipEvent_t */, void *stop /* hipEvent_t */);
 /* Tests / measurements only: which kernel layout ltr_mlp_pairwise_f32 takes where both apply.
  * 0 = automatic (the 4-wave tile kernel of csrc/ltr_mlp2.inc for batches of at least two queries per
  * CU-slot and for lists over 128 documents, else the 8-wave kernel of csrc/ltr_mlp.inc), 1 = the
@@ -423,6 +427,24 @@ int ltr_linear_sgd_steps_f32(int kind, float sigma, int K, const float *const *X
                              size_t workspace_bytes, void *stream);
 /* 1 when ltr_linear_sgd_steps_f32 takes this shape on the persistent kernel, 0 when it runs K per-step calls. */
 int ltr_linear_sgd_steps_plan(int kind, int B, int L, int F);
+/* The same step with the update applied LAZILY (examples/01-basic-usage.py:66-75, one batch per call as the DataLoader hands
+ * them over): the call computes this batch's per-query gradient rows into `workspace` and its losses into `loss`, and applies
+ * the update of the PREVIOUS call's batch first -- pending_B (> 0) = the number of queries of that batch, whose rows and losses
+ * `workspace` / `loss` still hold (the same buffers, the same F and lr) -- INSIDE this launch: its first workgroups reduce a
+ * column each in front of their tile burst (the arithmetic of the reduction launch, bit for bit), update W / bias in place,
+ * write the previous step's bucket [dW | db | loss_sum] and hand the new weights to every workgroup before the dot products.
+ * The reduction launch and one kernel boundary per step are gone; W, bias, buckets and losses are bit-identical to
+ * ltr_linear_sgd_step_f32 (grad_out = NULL).  The LAST batch's update is applied by ltr_linear_sgd_flush_f32 (also whenever
+ * the weights are to be read between steps).  pending_B = 0: nothing pending (the first step).  Shapes the register-tile
+ * kernel does not take and streams under capture flush first and run the plain launch. */
+int ltr_linear_sgd_lazy_step_f32(int kind, float sigma, const float *X, float *W, float *bias, const void *rel,
+                                 int rel_dtype, const int64_t *n, int B, int L, int F, float lr, float *loss,
+                                 float *bucket /* F + 2 */, void *workspace, size_t workspace_bytes, int pending_B,
+                                 void *stream);
+/* W -= lr * dW, bias -= lr * db of the batch whose rows `workspace` holds (pending_B queries; 0: nothing to do), bucket =
+ * [dW | db | loss_sum]: the reduction launch of ltr_linear_sgd_step_f32. */
+int ltr_linear_sgd_flush_f32(float *W, float *bias, int pending_B, int F, float lr, const float *loss, float *bucket /* F + 2 */,
+                             const void *workspace, void *stream);
 /* Tests only: != 0 makes every wait of the persistent kernel give up at once. */
 LTR_DEBUG_HOOK void ltr_debug_steps_force_timeout(int on);
 /* Tuning only: a device buffer of K * B * 8 int64 that later ltr_linear_sgd_steps_f32 launches fill with 100 MHz

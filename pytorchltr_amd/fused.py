@@ -328,6 +328,71 @@ def linear_sgd_steps(batches, weight, bias, lr, loss="hinge", return_losses=Fals
     return out + (lossv,) if return_losses else out
 
 
+class LazySGD:
+    """The reference's training loop body, one batch per call as the DataLoader hands them over, with the optimiser
+    step applied LAZILY (include/ltr_hip.h: ltr_linear_sgd_lazy_step_f32; examples/01-basic-usage.py:66-75):
+
+        opt = LazySGD(weight, bias, lr, loss="hinge")
+        for xs, ys, n in loader:
+            opt.step(xs, ys, n)         # loss_fn(Linear(F, 1)(xs), ys, n).mean().backward(); SGD.step()
+        opt.flush()                     # the last batch's update; also before the weights are read in between
+
+    `step` launches ONE kernel: it computes this batch's per-query gradient rows and applies the PREVIOUS batch's
+    update inside the same launch (its first workgroups sum that batch's rows and hand the new weights to every
+    workgroup before the dot products), so the reduction launch and a kernel boundary per step are gone.  Weights,
+    gradients and losses are bit-identical to the eager step's.  `weight` (F elements) / `bias` (one element) are
+    contiguous fp32 device tensors, updated in place; every batch must have the same (B, L, F)."""
+
+    def __init__(self, weight, bias, lr, loss="hinge"):
+        self.kind, self.sigma = _resolve_loss(loss)
+        if weight.dtype is not torch.float32 or not weight.is_contiguous() or not weight.is_cuda:
+            raise ValueError("weight must be a contiguous fp32 device tensor (it is updated in place)")
+        if bias is None or bias.dtype is not torch.float32 or bias.numel() != 1 or not bias.is_cuda:
+            raise ValueError("bias must be an fp32 device tensor of one element (it is updated in place)")
+        self.weight, self.bias, self.lr = weight, bias, float(lr)
+        self.pending = 0
+        self.shape = None
+        self.loss = self.bucket = self.ws = None
+
+    def step(self, xs, relevance, n):
+        X = _prepare_features(xs)
+        B, L, F = X.shape
+        if self.shape is None:
+            if self.weight.numel() != F:
+                raise ValueError("weight has %d elements, the rows %d features" % (self.weight.numel(), F))
+            self.shape = (B, L, F)
+            dev = X.device
+            self.loss = torch.empty(B, dtype=torch.float32, device=dev)
+            self.bucket = torch.zeros(F + 2, dtype=torch.float32, device=dev)
+            nb = _C.lib().ltr_linear_workspace_bytes(B, L, F)
+            self.ws = torch.empty(max(nb, 4) // 4, dtype=torch.float32, device=dev)
+        elif tuple(X.shape) != self.shape:
+            raise ValueError("every batch must have the shape of the first one %r (flush() and make a new LazySGD otherwise)" % (self.shape,))
+        r, nn = _labels_and_n(relevance, n, B, L, X.device)
+        with _C.device_ctx(X):
+            _C.check(_C.lib().ltr_linear_sgd_lazy_step_f32(
+                self.kind, float(self.sigma), _C.ptr(X), self.weight.data_ptr(), self.bias.data_ptr(), _C.ptr(r),
+                _C.label_dtype(r), _C.ptr(nn), B, L, F, self.lr, self.loss.data_ptr(), self.bucket.data_ptr(),
+                self.ws.data_ptr(), self.ws.numel() * 4, self.pending, _C.stream_of(X)))
+        for t in (X, r, nn):
+            t.record_stream(torch.cuda.current_stream(X.device))
+        self.pending = B
+
+    def flush(self):
+        """Applies the pending update; returns (mean loss, dW | db) of the last batch."""
+        if self.pending:
+            B, L, F = self.shape
+            with _C.device_ctx(self.ws):
+                _C.check(_C.lib().ltr_linear_sgd_flush_f32(
+                    self.weight.data_ptr(), self.bias.data_ptr(), self.pending, F, self.lr, self.loss.data_ptr(),
+                    self.bucket.data_ptr(), self.ws.data_ptr(), _C.stream_of(self.ws)))
+            self.pending = 0
+        if self.bucket is None:
+            return None
+        F = self.shape[2]
+        return self.bucket[F + 1] / float(self.shape[0]), self.bucket[:F + 1]
+
+
 # ---------------------------------------------------------------------------------------------
 # The Linear(F, 1) scorer on its own (unfused drop-in composition)
 # ---------------------------------------------------------------------------------------------

@@ -159,3 +159,108 @@ def test_sgd_step_refuses_a_deferred_allreduce():
         assert rc == _C.ERR_CONFIG
     finally:
         lib.ltr_overlap_destroy(handle)
+
+
+@pytest.mark.parametrize("shape", [("hinge", 1024, 128, 136), ("hinge", 300, 128, 136), ("ndcg2", 512, 128, 136),
+                                   ("logistic", 257, 100, 220), ("dcg_hinge", 600, 60, 64), ("arp2", 96, 200, 136),
+                                   ("hinge", 40, 1000, 220)])
+def test_lazy_sgd_steps_are_the_eager_steps_bit_for_bit(shape):
+    """ltr_linear_sgd_lazy_step_f32: step k + 1's launch applies step k's update itself (its first workgroups reduce the
+    pending batch's partial rows in front of their tile burst and hand the new weights over as tagged granules), the last
+    update by ltr_linear_sgd_flush_f32.  Over six batches of three in rotation: the weights after every flush point, every
+    step's bucket [dW | db | loss sum] and per-query losses are BIT-IDENTICAL to ltr_linear_sgd_step_f32's (which the test
+    above holds against the oracle's trajectory) -- on the register-tile shapes (the update rides in the launch) and on
+    shapes that flush first and run the plain launch (the last one: the cluster kernel)."""
+    from pytorchltr_amd import _C
+    lib = _C.lib()
+    dev = _dev()
+    kind, B, L, F = shape
+    kind_id = getattr(_C, kind.upper())
+    lr = 0.05
+    batches = []
+    for i in range(3):
+        s, y, n, X, W, b = synth(B, L, 11 + i, F=F)
+        batches.append([t.to(dev) for t in (X, y, n)])
+    _, _, _, _, W0, b0 = synth(B, L, 11, F=F)
+    st = _C.stream_of(batches[0][0])
+    nws = lib.ltr_linear_workspace_bytes(B, L, F)
+
+    def run(lazy):
+        Wd, bd = W0.clone().to(dev), b0.clone().to(dev)
+        ws = torch.full((nws // 4 + 64,), float("nan"), device=dev)
+        loss = torch.empty(B, device=dev)
+        bucket = torch.zeros(F + 2, device=dev)
+        trace = []
+        pending = 0
+        for k in range(6):
+            Xd, yd, nd = batches[k % 3]
+            if lazy:
+                _C.check(lib.ltr_linear_sgd_lazy_step_f32(kind_id, 1.0, Xd.data_ptr(), Wd.data_ptr(), bd.data_ptr(), yd.data_ptr(),
+                                                          _C.LABEL_I64, nd.data_ptr(), B, L, F, lr, loss.data_ptr(), bucket.data_ptr(),
+                                                          ws.data_ptr(), ws.numel() * 4, pending, st))
+                if pending:
+                    trace.append(("bucket", k - 1, bucket.clone()))      # (the previous step's, written by this launch)
+                pending = B
+                trace.append(("loss", k, loss.clone()))
+                if k in (2, 5):        # read the weights: flush first
+                    _C.check(lib.ltr_linear_sgd_flush_f32(Wd.data_ptr(), bd.data_ptr(), pending, F, lr, loss.data_ptr(),
+                                                          bucket.data_ptr(), ws.data_ptr(), st))
+                    pending = 0
+                    trace.append(("bucket", k, bucket.clone()))
+                    trace.append(("W", k, Wd.clone(), bd.clone()))
+            else:
+                _C.check(lib.ltr_linear_sgd_step_f32(kind_id, 1.0, Xd.data_ptr(), Wd.data_ptr(), bd.data_ptr(), yd.data_ptr(),
+                                                     _C.LABEL_I64, nd.data_ptr(), None, B, L, F, lr, loss.data_ptr(),
+                                                     bucket.data_ptr(), ws.data_ptr(), ws.numel() * 4, None, st))
+                trace.append(("loss", k, loss.clone()))
+                trace.append(("bucket", k, bucket.clone()))
+                if k in (2, 5):
+                    trace.append(("W", k, Wd.clone(), bd.clone()))
+        torch.cuda.synchronize()
+        _C.device_status()
+        return {(e[0], e[1]): [t.cpu().numpy() for t in e[2:]] for e in trace}
+
+    eager, lazy = run(False), run(True)
+    assert set(eager) == set(lazy)
+    for key in sorted(eager):
+        for a, b2 in zip(eager[key], lazy[key]):
+            assert np.all(np.isfinite(a)), key
+            assert np.array_equal(a, b2), key
+
+
+def test_lazy_sgd_module_trains_like_the_reference_loop():
+    """pytorchltr_amd.fused.LazySGD over five batches: the weights after flush() equal torch.optim.SGD on
+    loss_fn(nn.Linear(F, 1)(xs), ys, n).mean() through this package's loss module (itself held against the reference's
+    vectors) to fp32 summation order, and the returned mean loss / gradient are the last batch's."""
+    from pytorchltr_amd.fused import LazySGD
+    from pytorchltr_amd.loss import PairwiseLogisticLoss
+    dev = _dev()
+    B, L, F = 300, 100, 136            # (the logistic loss: smooth -- the hinge's trajectory forks at every pair on the margin)
+    lr = 0.05
+    data = []
+    for i in range(5):
+        s, y, n, X, W, b = synth(B, L, 31 + i, F=F)
+        data.append((X.to(dev), y.to(dev), n.to(dev)))
+    _, _, _, _, W0, b0 = synth(B, L, 31, F=F)
+    w, bias = W0.clone().to(dev), b0.clone().to(dev)
+    opt = LazySGD(w, bias, lr, loss="logistic")
+    for xs, ys, n in data:
+        opt.step(xs, ys, n)
+    mean_loss, grad = opt.flush()
+    model = torch.nn.Linear(F, 1).to(dev)
+    with torch.no_grad():
+        model.weight.copy_(W0.reshape(1, F))
+        model.bias.copy_(b0)
+    sgd = torch.optim.SGD(model.parameters(), lr=lr)
+    loss_fn = PairwiseLogisticLoss()
+    last = None
+    for xs, ys, n in data:
+        sgd.zero_grad()
+        last = loss_fn(model(xs), ys, n).mean()
+        last.backward()
+        sgd.step()
+    torch.cuda.synchronize()
+    assert torch.allclose(w, model.weight.detach().reshape(F), rtol=1e-4, atol=1e-6)
+    assert torch.allclose(bias, model.bias.detach(), rtol=1e-4, atol=1e-6)
+    assert torch.allclose(mean_loss, last.detach(), rtol=1e-5)
+    assert torch.allclose(grad[:F], model.weight.grad.reshape(F), rtol=1e-4, atol=1e-6)
