@@ -46,7 +46,7 @@ extern "C" {
 #define LTR_DEBUG_HOOK
 #endif
 
-#define LTR_VERSION 113 /* 0.1.13 */
+#define LTR_VERSION 114 /* 0.1.14 */
 
 /* Loss kinds: one per class exported by pytorchltr/loss/__init__.py:1-7. */
 enum ltr_loss_kind {

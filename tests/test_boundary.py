@@ -39,7 +39,7 @@ def test_header_symbols_all_exported_and_bound():
     # the ctypes table covers exactly the header
     assert sorted(_C.SIGNATURES) == declared
     lib = _C.lib()
-    assert lib.ltr_version() == 113
+    assert lib.ltr_version() == 114
     assert lib.ltr_max_list_len() >= 1024
     assert b"NULL" in lib.ltr_error_string(-1)
     assert lib.ltr_linear_workspace_bytes(1024, 128, 136) >= 1024 * 137 * 4
