@@ -319,6 +319,7 @@ def lazy_kernel_us(fs, batches, nbuf, count=400):
     for i in range(count):
         lib.ltr_debug_kernel_events(evs[2 * i], evs[2 * i + 1])
         fs.lazy_step(batches[i % nbuf])
+    lib.ltr_debug_kernel_events(None, None)          # (disarmed, whatever the last launch did with the pair)
     fs.lazy_flush()
     torch.cuda.synchronize()
     per = []

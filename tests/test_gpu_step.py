@@ -163,7 +163,7 @@ def test_sgd_step_refuses_a_deferred_allreduce():
 
 @pytest.mark.parametrize("shape", [("hinge", 1024, 128, 136), ("hinge", 300, 128, 136), ("ndcg2", 512, 128, 136),
                                    ("logistic", 257, 100, 220), ("dcg_hinge", 600, 60, 64), ("arp2", 96, 200, 136),
-                                   ("hinge", 40, 1000, 220)])
+                                   ("hinge", 300, 10, 700), ("ndcg1", 1, 128, 136), ("hinge", 40, 1000, 220)])
 def test_lazy_sgd_steps_are_the_eager_steps_bit_for_bit(shape):
     """ltr_linear_sgd_lazy_step_f32: step k + 1's launch applies step k's update itself (its first workgroups reduce the
     pending batch's partial rows in front of their tile burst and hand the new weights over as tagged granules), the last
@@ -264,3 +264,38 @@ def test_lazy_sgd_module_trains_like_the_reference_loop():
     assert torch.allclose(bias, model.bias.detach(), rtol=1e-4, atol=1e-6)
     assert torch.allclose(mean_loss, last.detach(), rtol=1e-5)
     assert torch.allclose(grad[:F], model.weight.grad.reshape(F), rtol=1e-4, atol=1e-6)
+
+
+def test_lazy_sgd_step_that_never_gets_its_weights_raises_the_status():
+    """The weights' hand-over inside the lazy launch is a bounded wait: with the waits forced to give up (ltr_debug_force_timeout)
+    the step scores with NaN weights and raises LTR_ERR_TIMEOUT in the sticky device status instead of hanging; once the status
+    has been cleared the next steps run clean."""
+    from pytorchltr_amd import _C
+    lib = _C.lib()
+    dev = _dev()
+    B, L, F = 300, 128, 136
+    s, y, n, X, W, b = synth(B, L, 3, F=F)
+    Xd, yd, nd, Wd, bd = X.to(dev), y.to(dev), n.to(dev), W.clone().to(dev), b.clone().to(dev)
+    ws = torch.zeros(lib.ltr_linear_workspace_bytes(B, L, F) // 4 + 64, device=dev)
+    loss = torch.empty(B, device=dev)
+    bucket = torch.zeros(F + 2, device=dev)
+    st = _C.stream_of(Xd)
+
+    def step(pending):
+        return lib.ltr_linear_sgd_lazy_step_f32(_C.HINGE, 1.0, Xd.data_ptr(), Wd.data_ptr(), bd.data_ptr(), yd.data_ptr(), _C.LABEL_I64,
+                                                nd.data_ptr(), B, L, F, 0.01, loss.data_ptr(), bucket.data_ptr(), ws.data_ptr(),
+                                                ws.numel() * 4, pending, st)
+    assert step(0) == 0
+    lib.ltr_debug_force_timeout(1)
+    try:
+        assert step(B) == 0
+        torch.cuda.synchronize()
+    finally:
+        lib.ltr_debug_force_timeout(0)
+    assert lib.ltr_device_status(1) == _C.ERR_TIMEOUT       # (the step scored with NaN weights: whatever it wrote is invalid)
+    # a clean restart
+    Wd.copy_(W.to(dev)); bd.copy_(b.to(dev))
+    assert step(0) == 0 and step(B) == 0
+    torch.cuda.synchronize()
+    _C.device_status()
+    assert np.all(np.isfinite(loss.cpu().numpy())) and np.all(np.isfinite(Wd.cpu().numpy()))
