@@ -288,8 +288,8 @@ class FusedStep:
 
     def lazy_flush(self, lr=SGD_LR):
         self._C.check(self.lib.ltr_linear_sgd_flush_f32(
-            self.W.data_ptr(), self.bias.data_ptr(), self.pending, self.F, float(lr), self.lossv.data_ptr(),
-            self.flat.data_ptr(), self.part.data_ptr(), self._stream()))
+            self.kind_id, self.W.data_ptr(), self.bias.data_ptr(), self.pending, self.L, self.F, float(lr),
+            self.lossv.data_ptr(), self.flat.data_ptr(), self.part.data_ptr(), self._stream()))
         self.pending = 0
 
     def step_two_calls(self, batch, accumulate=False, flat=None):

@@ -435,16 +435,19 @@ int ltr_linear_sgd_steps_plan(int kind, int B, int L, int F);
  * write the previous step's bucket [dW | db | loss_sum] and hand the new weights to every workgroup before the dot products.
  * The reduction launch and one kernel boundary per step are gone; W, bias, buckets and losses are bit-identical to
  * ltr_linear_sgd_step_f32 (grad_out = NULL).  The LAST batch's update is applied by ltr_linear_sgd_flush_f32 (also whenever
- * the weights are to be read between steps).  pending_B = 0: nothing pending (the first step).  Shapes the register-tile
+ * the weights are to be read between steps).  pending_B = 0: nothing pending (the first step).  `workspace` belongs to the lazy
+ * entry points between a step and the flush (on the shapes it takes along the step keeps its rows column-group major); X must be
+ * 16-byte aligned when F % 4 == 0 (LTR_ERR_CONFIG otherwise).  Shapes the register-tile
  * kernel does not take and streams under capture flush first and run the plain launch. */
 int ltr_linear_sgd_lazy_step_f32(int kind, float sigma, const float *X, float *W, float *bias, const void *rel,
                                  int rel_dtype, const int64_t *n, int B, int L, int F, float lr, float *loss,
                                  float *bucket /* F + 2 */, void *workspace, size_t workspace_bytes, int pending_B,
                                  void *stream);
-/* W -= lr * dW, bias -= lr * db of the batch whose rows `workspace` holds (pending_B queries; 0: nothing to do), bucket =
- * [dW | db | loss_sum]: the reduction launch of ltr_linear_sgd_step_f32. */
-int ltr_linear_sgd_flush_f32(float *W, float *bias, int pending_B, int F, float lr, const float *loss, float *bucket /* F + 2 */,
-                             const void *workspace, void *stream);
+/* W -= lr * dW, bias -= lr * db of the batch whose rows `workspace` holds (pending_B queries of the same kind / L / F as the
+ * lazy step that wrote them -- the step keeps its rows in a layout of its own on the shapes it takes along, which follows from
+ * (kind, pending_B, L, F); 0: nothing to do), bucket = [dW | db | loss_sum]: the reduction launch of ltr_linear_sgd_step_f32. */
+int ltr_linear_sgd_flush_f32(int kind, float *W, float *bias, int pending_B, int L, int F, float lr, const float *loss,
+                             float *bucket /* F + 2 */, const void *workspace, void *stream);
 /* Tests only: != 0 makes every wait of the persistent kernel give up at once. */
 LTR_DEBUG_HOOK void ltr_debug_steps_force_timeout(int on);
 /* Tuning only: a device buffer of K * B * 8 int64 that later ltr_linear_sgd_steps_f32 launches fill with 100 MHz

@@ -384,8 +384,8 @@ class LazySGD:
             B, L, F = self.shape
             with _C.device_ctx(self.ws):
                 _C.check(_C.lib().ltr_linear_sgd_flush_f32(
-                    self.weight.data_ptr(), self.bias.data_ptr(), self.pending, F, self.lr, self.loss.data_ptr(),
-                    self.bucket.data_ptr(), self.ws.data_ptr(), _C.stream_of(self.ws)))
+                    self.kind, self.weight.data_ptr(), self.bias.data_ptr(), self.pending, L, F, self.lr,
+                    self.loss.data_ptr(), self.bucket.data_ptr(), self.ws.data_ptr(), _C.stream_of(self.ws)))
             self.pending = 0
         if self.bucket is None:
             return None

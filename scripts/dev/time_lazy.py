@@ -22,9 +22,9 @@ for case in (sys.argv[1:] or ["hinge:1024x128x136", "ndcg2:1024x128x136", "hinge
         _C.check(lib.ltr_linear_sgd_lazy_step_f32(fs.kind_id, 1.0, b["X"].data_ptr(), fs.W.data_ptr(), fs.bias.data_ptr(), b["rel"].data_ptr(),
                                                   _C.LABEL_I64, b["n"].data_ptr(), B, L, F, bench.SGD_LR, fs.lossv.data_ptr(), fs.flat.data_ptr(),
                                                   fs.part.data_ptr(), fs.ws_bytes, state["pending"], st))
-        state["pending"] = B
+        state["pending"] = int(os.environ.get("LTR_TIME_LAZY_PEND", B))      # (timing experiment: a pending batch of fewer rows)
     def flush():
-        _C.check(lib.ltr_linear_sgd_flush_f32(fs.W.data_ptr(), fs.bias.data_ptr(), state["pending"], F, bench.SGD_LR, fs.lossv.data_ptr(),
+        _C.check(lib.ltr_linear_sgd_flush_f32(fs.kind_id, fs.W.data_ptr(), fs.bias.data_ptr(), state["pending"], L, F, bench.SGD_LR, fs.lossv.data_ptr(),
                                               fs.flat.data_ptr(), fs.part.data_ptr(), st))
         state["pending"] = 0
     out = [case]

@@ -203,7 +203,7 @@ def test_lazy_sgd_steps_are_the_eager_steps_bit_for_bit(shape):
                 pending = B
                 trace.append(("loss", k, loss.clone()))
                 if k in (2, 5):        # read the weights: flush first
-                    _C.check(lib.ltr_linear_sgd_flush_f32(Wd.data_ptr(), bd.data_ptr(), pending, F, lr, loss.data_ptr(),
+                    _C.check(lib.ltr_linear_sgd_flush_f32(kind_id, Wd.data_ptr(), bd.data_ptr(), pending, L, F, lr, loss.data_ptr(),
                                                           bucket.data_ptr(), ws.data_ptr(), st))
                     pending = 0
                     trace.append(("bucket", k, bucket.clone()))
