@@ -396,6 +396,25 @@ def measure_config(name, B, L, F, kind, dev, seed0, full=False, events=False, la
     if events:
         avg, med, mn = time_events(lambda i: fs.kernel(batches[i % nbuf]), 100)
         res["kernel_us_single_launch_event_pair"] = {"avg": avg, "median": med, "min": mn}
+    # the synchronous-SGD step as ONE launch (the lazy step: ltr_linear_sgd_lazy_step_f32) where the register tile takes the shape:
+    # eager back-to-back steps + the flush, wall clock (a captured graph cannot carry the lazy step's tag) -- next to step_us,
+    # the graph-timed two launches without the weight update
+    if fs.plan == "linear_regtile_kernel" and hasattr(fs.lib, "ltr_linear_sgd_lazy_step_f32") and not full:
+        for i in range(2 * nbuf):
+            fs.lazy_step(batches[i % nbuf])
+        fs.lazy_flush()
+        torch.cuda.synchronize()
+        per = []
+        K = 2000
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for i in range(K):
+                fs.lazy_step(batches[i % nbuf])
+            fs.lazy_flush()
+            torch.cuda.synchronize()
+            per.append((time.perf_counter() - t0) / K * 1e6)
+        res["lazy_sgd_step_us"] = sorted(per)[1]
+        res["lazy_sgd_step_queries_per_s"] = B / (res["lazy_sgd_step_us"] * 1e-6)
     return res, fs, batches
 
 
