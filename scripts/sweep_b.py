@@ -43,8 +43,51 @@ for kind_name, kind in (("hinge", _C.HINGE), ("ndcg2", _C.NDCG2)):
             alg_f = B * (4 * L * F + 8 * L + 12 + 4 * (F + 1))
             real_f = int(n.sum()) * (4 * F + 8) + B * (12 + 4 * (F + 1))
             alg_l = B * (16 * L + 16)
+            # round 5: the synchronous-SGD step on this (warm, single) batch, eager wall clock -- as two launches
+            # (ltr_linear_sgd_step_f32) and with the update riding in the next launch (ltr_linear_sgd_lazy_step_f32 + one flush;
+            # batches of more than one round of workgroups flush first and run the plain launch: the same two launches)
+            import time
+            bucket = torch.zeros(F + 2, device=dev)
+            Wc, bc = W.clone(), bias.clone()
+            steps = 400 if B <= 16384 else 40
+
+            def sgd2():
+                _C.check(lib.ltr_linear_sgd_step_f32(kind, 1.0, X.data_ptr(), Wc.data_ptr(), bc.data_ptr(), rel.data_ptr(), 0,
+                                                     n.data_ptr(), None, B, L, F, 1e-6, loss.data_ptr(), bucket.data_ptr(),
+                                                     part.data_ptr(), part.numel() * 4, None, cs()))
+            pend = [0]
+
+            def sgdl():
+                _C.check(lib.ltr_linear_sgd_lazy_step_f32(kind, 1.0, X.data_ptr(), Wc.data_ptr(), bc.data_ptr(), rel.data_ptr(), 0,
+                                                          n.data_ptr(), B, L, F, 1e-6, loss.data_ptr(), bucket.data_ptr(),
+                                                          part.data_ptr(), part.numel() * 4, pend[0], cs()))
+                pend[0] = B
+
+            def flush():
+                _C.check(lib.ltr_linear_sgd_flush_f32(kind, Wc.data_ptr(), bc.data_ptr(), pend[0], L, F, 1e-6, loss.data_ptr(),
+                                                      bucket.data_ptr(), part.data_ptr(), cs()))
+                pend[0] = 0
+            st = {}
+            for name, fn, fin in (("two_launch", sgd2, None), ("lazy", sgdl, flush)):
+                for _ in range(10):
+                    fn()
+                if fin:
+                    fin()
+                torch.cuda.synchronize()
+                best = 1e30
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    for _i in range(steps):
+                        fn()
+                    if fin:
+                        fin()
+                    torch.cuda.synchronize()
+                    best = min(best, (time.perf_counter() - t0) / steps * 1e6)
+                st[name] = best
             rows.append(dict(kind=kind_name, full_lists=full, B=B, fused_us=tf, fused_qps=B / tf * 1e6,
                              fused_alg_GBs=alg_f / tf / 1e3, fused_read_GBs=real_f / tf / 1e3,
-                             loss_us=tl, loss_qps=B / tl * 1e6, loss_alg_GBs=alg_l / tl / 1e3))
+                             loss_us=tl, loss_qps=B / tl * 1e6, loss_alg_GBs=alg_l / tl / 1e3,
+                             sgd_step_two_launch_us=st["two_launch"], sgd_step_lazy_us=st["lazy"],
+                             sgd_step_lazy_qps=B / st["lazy"] * 1e6))
             print(json.dumps(rows[-1]), flush=True)
             del X
