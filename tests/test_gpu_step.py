@@ -163,7 +163,10 @@ def test_sgd_step_refuses_a_deferred_allreduce():
 
 @pytest.mark.parametrize("shape", [("hinge", 1024, 128, 136), ("hinge", 300, 128, 136), ("ndcg2", 512, 128, 136),
                                    ("logistic", 257, 100, 220), ("dcg_hinge", 600, 60, 64), ("arp2", 96, 200, 136),
-                                   ("hinge", 300, 10, 700), ("ndcg1", 1, 128, 136), ("hinge", 40, 1000, 220)])
+                                   ("hinge", 300, 10, 700), ("ndcg1", 1, 128, 136), ("hinge", 40, 1000, 220),
+                                   # more queries than one round of workgroups: the column-group rows, flushed by the reducers on
+                                   # their own in front of a plain launch
+                                   ("hinge", 2500, 64, 136), ("logistic", 5000, 40, 64)])
 def test_lazy_sgd_steps_are_the_eager_steps_bit_for_bit(shape):
     """ltr_linear_sgd_lazy_step_f32: step k + 1's launch applies step k's update itself (its first workgroups reduce the
     pending batch's partial rows in front of their tile burst and hand the new weights over as tagged granules), the last
