@@ -25,14 +25,16 @@ n[b] real rows of every query are read -- next to the padded-formula figure of S
 Timing.  The timed region holds max(K, enough steps for >= 50 ms) steps, bracketed by barrier +
 synchronize; it is repeated 5 times and the MEDIAN repeat is reported (max over ranks per repeat).
 
-N > 1: one process per GPU, queries are independent units -> no data-path collective.  Weak
-scaling by default (every rank owns its own B queries per step); `--shard` splits BASELINE's global
-batch over the ranks instead (C4: 32 queries / GPU at N = 8).  The only exchange is the scorer
-gradient, ONE all-reduce PER STEP of the bucket [dW (F) | db | loss_sum] over RCCL (what north_star /
-SURVEY.md 8(e) specify; config.allreduce_every = 1): step i's all-reduce is enqueued
-by the C ABI behind the step's kernels (ltr_linear_step_f32 + pytorchltr_amd.distributed.RcclOverlap;
-the overlapped variants measured slower on this stack, see main()).  `--accum K` (K > 1) is the gradient-accumulation variant -- K micro-batch
-steps accumulated in HBM per all-reduce -- reported in `extra` at N > 1, never the headline.
+N > 1: one process per GPU (the driver's `torch.distributed.run` launch; run BARE, `bench.py --gpus N` starts its N ranks
+itself; WORLD_SIZE must equal --gpus, and the line's n_gpus is the number of ranks that ran, config.devices where).  Queries are
+independent units -> no data-path collective.  Weak scaling by default (every rank owns its own B queries per step); `--shard`
+splits BASELINE's global batch over the ranks instead (C4: 32 queries / GPU at N = 8).  The only exchange is the scorer
+gradient, ONE all-reduce PER STEP of [dW (F) | db | loss_sum] (north_star / SURVEY.md 8(e); config.allreduce_every = 1).  The
+headline step is ONE launch per rank at every N (ltr_linear_sgd_lazy_step_dp_f32: the all-reduce rides in the fused launch's
+reducer workgroups, through HIP-IPC mapped peer mailboxes over xGMI); the same steps with the mailbox all-reduce as a launch of
+its own and with an in-stream ncclAllReduce (RCCL) are timed next to it (extra.mailbox_three_launch_step_us,
+extra.rccl_instream_step_us); a trial under a short time budget decides, on every rank alike, whether the headline falls back to
+them (config.allreduce says which ran).  `--accum K` (K > 1) is the gradient-accumulation variant, reported in `extra` at N > 1.
 
 Prints ONE JSON line on rank 0 (metric, value, ..., roofline, cpu_baseline, extra).
 """
@@ -67,6 +69,9 @@ WORKLOADS = {
     "c3": (1024, 128, 136, "ndcg2"),
     "c4": (256, 1000, 220, "dcg_hinge"),
     "c5": (512, 512, 700, "hinge"),
+    # (not a BASELINE config: C2's shape at half the batch, for FUNCTIONAL multi-rank runs with the ranks on one GPU --
+    # tests/test_gpu_bench.py --, where the ranks' grids must be resident side by side)
+    "c2s": (512, 128, 136, "hinge"),
 }
 PLAN_NAMES = {1: "linear_regtile_kernel", 2: "linear_cluster_kernel", 3: "linear_pairwise_kernel",
               4: "linear_parts_kernel"}
@@ -243,6 +248,14 @@ class FusedStep:
         self.go = torch.full((B,), 1.0 / (B * n_gpus), device=dev)
         self.plan = PLAN_NAMES.get(self.lib.ltr_linear_fused_plan(self.kind_id, B, L, F), "?")
         self.pending = 0
+        self.mailbox = None                  # N > 1: the ltr_mailbox_* handle of the data-parallel lazy step
+        self.lazy_scale = 1.0 / (B * n_gpus)
+        self._W0, self._b0 = self.W.clone(), self.bias.clone()
+
+    def reset_weights(self):
+        self.W.copy_(self._W0)
+        self.bias.copy_(self._b0)
+        self.pending = 0
 
     @staticmethod
     def _stream():
@@ -278,18 +291,20 @@ class FusedStep:
             None, self._stream()))
 
     def lazy_step(self, batch, lr=SGD_LR):
-        """The same step, the update applied lazily (ltr_linear_sgd_lazy_step_f32): ONE launch -- this batch's per-query
-        gradient rows, and the previous batch's reduction + W -= lr * dW inside it; lazy_flush() applies the last one."""
-        self._C.check(self.lib.ltr_linear_sgd_lazy_step_f32(
+        """The same step, the update applied lazily (ltr_linear_sgd_lazy_step_dp_f32): ONE launch -- this batch's per-query
+        gradient rows, and the previous batch's reduction + W -= lr * dW inside it; lazy_flush() applies the last one.
+        With self.mailbox set (N > 1) the reducers all-reduce their column sums over the ranks inside the same launch."""
+        self._C.check(self.lib.ltr_linear_sgd_lazy_step_dp_f32(
             self.kind_id, 1.0, batch["X"].data_ptr(), self.W.data_ptr(), self.bias.data_ptr(),
             batch["rel"].data_ptr(), self._C.LABEL_I64, batch["n"].data_ptr(), self.B, self.L, self.F, float(lr),
-            self.lossv.data_ptr(), self.flat.data_ptr(), self.part.data_ptr(), self.ws_bytes, self.pending, self._stream()))
+            self.lossv.data_ptr(), self.flat.data_ptr(), self.part.data_ptr(), self.ws_bytes, self.pending,
+            self.lazy_scale, self.mailbox, self._stream()))
         self.pending = self.B
 
     def lazy_flush(self, lr=SGD_LR):
-        self._C.check(self.lib.ltr_linear_sgd_flush_f32(
-            self.kind_id, self.W.data_ptr(), self.bias.data_ptr(), self.pending, self.L, self.F, float(lr),
-            self.lossv.data_ptr(), self.flat.data_ptr(), self.part.data_ptr(), self._stream()))
+        self._C.check(self.lib.ltr_linear_sgd_flush_dp_f32(
+            self.kind_id, self.W.data_ptr(), self.bias.data_ptr(), self.pending, self.L, self.F, float(lr), self.lazy_scale,
+            self.lossv.data_ptr(), self.flat.data_ptr(), self.part.data_ptr(), self.mailbox, self._stream()))
         self.pending = 0
 
     def step_two_calls(self, batch, accumulate=False, flat=None):
@@ -571,6 +586,49 @@ def cpu_baseline(kind, B, L, F, reps=5):
     }
 
 
+def lazy_dp_trial(fs, mb, batches, nbuf, dist, dev):
+    """A few data-parallel lazy steps under a SHORT time budget before they are timed: the launch's reducers wait for their
+    peers inside the fused kernel, which has only ever run between processes on one device (tests/test_gpu_lazy_dp.py) -- if
+    anything is off (a poll gives up, the ranks' weights differ) every rank falls back to the three-launch mailbox step.
+    Returns None when fine, else the reason; the weights are put back either way."""
+    lib = fs.lib
+    why = None
+    old = lib.ltr_mailbox_set_timeout_ms(int(os.environ.get("LTR_MAILBOX_CHECK_TIMEOUT_MS", "5000")))
+    fs.mailbox = mb.mbox
+    try:
+        for i in range(2 * nbuf):
+            fs.lazy_step(batches[i % nbuf])
+        fs.lazy_flush()
+        torch.cuda.synchronize()
+        if lib.ltr_device_status(0) != 0:
+            why = "device status %d (an in-launch wait gave up)" % lib.ltr_device_status(0)
+        elif not bool(torch.isfinite(fs.W).all()):
+            why = "non-finite weights"
+    except Exception as exc:  # pragma: no cover - depends on the runtime
+        why = repr(exc)[:160]
+    finally:
+        if old > 0:
+            lib.ltr_mailbox_set_timeout_ms(old)
+    if why is None:
+        wb = [None] * dist.get_world_size()
+        dist.all_gather_object(wb, torch.cat([fs.W, fs.bias]).cpu().numpy().tobytes())
+        if not all(x == wb[0] for x in wb):
+            why = "weights differ across ranks"
+    else:
+        dist.all_gather_object([None] * dist.get_world_size(), b"")          # (the same collectives on every rank)
+    if not mb._all_agree(1 if why is None else 0):
+        why = why or "another rank's trial failed"
+    try:
+        torch.cuda.synchronize()
+    except Exception:  # pragma: no cover
+        pass
+    if why is not None:
+        lib.ltr_device_status(1)
+        fs.mailbox = None
+    fs.reset_weights()
+    return why
+
+
 def allreduce_probe():
     """Internal (--allreduce-probe): one rank, RCCL process group forced; times the eager
     all-reduce of the (F+3)-float bucket and the step with it.  Printed as one JSON line."""
@@ -686,6 +744,37 @@ def allreduce_probe():
     print(json.dumps(out))
 
 
+def note(msg):
+    """Progress on stderr (LTR_BENCH_VERBOSE=1): where a multi-rank run is, should it stall."""
+    if os.environ.get("LTR_BENCH_VERBOSE") == "1":
+        sys.stderr.write("[bench r%s %.1fs] %s\n" % (os.environ.get("RANK", "0"), time.perf_counter(), msg))
+        sys.stderr.flush()
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` run bare (no launcher): N ranks of this very command, one per GPU (RANK = LOCAL_RANK = 0 .. N-1,
+    rendezvous on 127.0.0.1), rank 0's JSON line passed through.  The driver's `torch.distributed.run` launch sets WORLD_SIZE
+    and never comes here."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    line, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(line.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit("bench.py --gpus %d: rank exit codes %r" % (n, rcs))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -705,6 +794,13 @@ def main():
     args = ap.parse_args()
     if args.allreduce_probe:
         return allreduce_probe()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus)        # run bare: one rank per GPU, started here
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit("bench.py --gpus %d launched with WORLD_SIZE=%s: the launcher's rank count and --gpus must agree "
+                         "(the line's n_gpus is the number of ranks that ran)" % (args.gpus, os.environ.get("WORLD_SIZE")))
 
     # stdout carries exactly ONE line, the JSON result: RCCL prints a version banner to stdout when
     # a communicator is created, and other libraries may chat too -- send file descriptor 1 to
@@ -718,6 +814,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback in the product path)")
+    backend = os.environ.get("LTR_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        # (LTR_BENCH_BACKEND=gloo: the N > 1 code path run functionally on a box with fewer GPUs than ranks -- ranks share
+        # devices round robin; RCCL itself wants one device per rank)
+        local_rank %= torch.cuda.device_count()
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d: LOCAL_RANK %d but %d GPU(s) visible (one rank per GPU; LTR_BENCH_BACKEND=gloo shares devices "
+                         "for functional runs)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -727,12 +831,17 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         # (LTR_BENCH_BACKEND=gloo with every rank on LOCAL_RANK 0: the N > 1 code path -- mailbox all-reduce, SGD step,
         # max-over-ranks timing -- run functionally by several processes on ONE GPU; tests/test_gpu_bench.py)
-        backend = os.environ.get("LTR_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    n_gpus = world
+    # n_gpus = the ranks that actually run (and the devices they sit on, for the line)
+    n_gpus = dist.get_world_size() if dist is not None else 1
+    devices = ["%s:%d %s" % (os.uname().nodename, local_rank, torch.cuda.get_device_name(dev))]
+    if dist is not None and n_gpus > 1:
+        gathered = [None] * n_gpus
+        dist.all_gather_object(gathered, devices[0])
+        devices = gathered
     if dist is not None:
         # ProcessGroupNCCL's watchdog thread polls HIP events; an event query while another
         # thread is capturing aborts the process ("operation not permitted when stream is
@@ -783,54 +892,82 @@ def main():
         def step(i):
             fs.sgd_step(batches[i % nbuf])
     elif accum == 1:
-        # one all-reduce per step, overlapped: step i writes bucket i % 2, its all-reduce is enqueued
-        # asynchronously and runs under step i + 1; the compute stream waits for it only when the bucket
-        # comes round again
-        # ONE all-reduce per step, issued by the C ABI itself behind the step's kernels (ltr_linear_step_f32
-        # with an in-stream handle: one ncclAllReduce call on the step's stream, RCCL communicator of its
-        # own, no Python / c10d bookkeeping in the step).  Measured at one rank (extra.allreduce_probe_1rank):
-        # c10d blocking all_reduce 24-31 us per step, c10d async + double buffering 39-42 (its host call
-        # alone is 22 us), a side stream + events 32-34 (a wait on a just-recorded event costs the host
-        # 6.5 us on ROCm 7.2, twice per step, helper thread or not) -- against 14.9 in-stream, where the
-        # collective's own latency stays on the stream.
+        # ONE gradient all-reduce per step (synchronous SGD: step i + 1 scores with the weights step i's all-reduced gradient
+        # produced -- the collective is on the critical path).  LTR_BENCH_ALLREDUCE selects how it is carried:
+        #   "lazy" (default)  ltr_linear_sgd_lazy_step_dp_f32: ONE launch per step and rank, as at N = 1 -- the reducer
+        #                     workgroups in front of the fused launch all-reduce their column sums through the peers' HIP-IPC
+        #                     mapped mailboxes, the first query's workgroup writes the weights;
+        #   "mailbox"         ltr_linear_sgd_step_f32 + mailbox handle: kernel, reduction, mailbox all-reduce + update (3 launches);
+        #   "instream"        ... + RCCL handle: kernel, reduction, ncclAllReduce on the step's stream, update (4 launches);
+        #   "overlap" / "c10d" RCCL on a side stream (delayed gradient) / torch.distributed per step.
+        # Each falls back to the next on EVERY rank when it cannot be set up or its check fails; the line says which ran,
+        # and extra carries the others next to it (below).
         from pytorchltr_amd.distributed import MailboxOverlap, OverlappedBucketAllReduce, RcclOverlap
-        # the collective of the step: "mailbox" (default: the hand-written small-message all-reduce over HIP-IPC
-        # mapped peer mailboxes, include/ltr_hip.h; falls back to "instream" on every rank when it cannot be set up
-        # or its self-check against torch.distributed disagrees), "instream" (one ncclAllReduce on the step's stream,
-        # RCCL communicator of its own), "overlap" (RCCL on a side stream, delayed gradient), "c10d"
-        mode = os.environ.get("LTR_BENCH_ALLREDUCE", "mailbox")
+        mode = os.environ.get("LTR_BENCH_ALLREDUCE", "lazy")
         raw = None
-        if mode == "mailbox":
+        fell_back = []
+        if mode in ("lazy", "mailbox"):
             raw = MailboxOverlap(F, count=B, device=dev)
             if not raw.ok:
-                sys.stderr.write("[bench] mailbox all-reduce unavailable (%s): RCCL in-stream\n" % raw.why)
+                fell_back.append("mailbox all-reduce unavailable (%s)" % raw.why)
                 raw.close()
                 raw, mode = None, "instream"
+        if raw is not None and mode == "lazy":
+            # (ranks sharing ONE device -- functional runs only -- must be resident side by side: a launch whose reducers wait for a
+            # peer whose launch cannot become resident never ends.  One rank per GPU, as the driver launches, is never affected.)
+            shared = max(devices.count(d) for d in devices)
+            if shared > 1 and shared * (B + (F + 4) // 4 + 1) > 4 * CU_COUNT:
+                fell_back.append("%d ranks share a device and their launches do not fit it together" % shared)
+                mode = "mailbox"
+        if raw is not None and mode == "lazy":
+            note("mailbox up; trial of the data-parallel lazy step")
+            why = lazy_dp_trial(fs, raw, batches, nbuf, dist, dev)
+            note("trial: %s" % (why or "ok"))
+            if why is not None:
+                fell_back.append("data-parallel lazy step: %s" % why)
+                mode = "mailbox"
         if raw is None and mode != "c10d":
             raw = RcclOverlap(F, count=B, device=dev, depth=(0 if mode == "instream" else 2))
+        if fell_back:
+            sys.stderr.write("[bench] rank %d: %s -> %s\n" % (rank, "; ".join(fell_back), mode))
         if raw is not None and raw.ok:
             red = raw
-            if mode == "mailbox":
-                allreduce_impl = ("ltr_linear_sgd_step_f32 + mailbox all-reduce: one kernel per rank stores the bucket's tagged "
-                                  "granules into every peer's HIP-IPC-mapped mailbox, adds the arrivals in rank order and applies "
-                                  "the weight update (no collective library in the step)")
-            else:
-                allreduce_impl = ("ltr_linear_step_f32 + %s handle: ncclAllReduce %s (RCCL communicator of its own)" % (
-                    ("in-stream", "on the step's stream behind its kernels") if mode == "instream" else
-                    ("overlap", "on a side stream under the next step")))
+            if mode == "lazy":
+                allreduce_impl = ("ltr_linear_sgd_lazy_step_dp_f32: ONE launch per step and rank -- the reducer workgroups in front of "
+                                  "the fused launch sum the previous step's gradient rows, post their column sums as tagged granules "
+                                  "into every peer's HIP-IPC-mapped mailbox, add the arrivals in rank order and hand the new weights "
+                                  "to the launch (no collective library, no extra launch in the step)")
+                fs.mailbox = raw.mbox
 
-            def step(i):
-                b = batches[i % nbuf]
-                if mode in ("instream", "mailbox"):      # synchronous SGD: kernels, all-reduce, W -= lr * dW -- one C-ABI call
-                    raw.sgd_step(fs.kind_id, 1.0, b["X"], fs.W, fs.bias, b["rel"], _C.LABEL_I64, b["n"], fs.go, B, L, F,
-                                 SGD_LR, fs.lossv, fs.part)
+                def step(i):
+                    fs.lazy_step(batches[i % nbuf])
+
+                def finish():
+                    fs.lazy_flush()
+            else:
+                if mode == "mailbox":
+                    allreduce_impl = ("ltr_linear_sgd_step_f32 + mailbox all-reduce: one kernel per rank stores the bucket's tagged "
+                                      "granules into every peer's HIP-IPC-mapped mailbox, adds the arrivals in rank order and applies "
+                                      "the weight update (3 launches per step, no collective library in the step)")
                 else:
-                    raw.step(i, fs.kind_id, 1.0, b["X"], fs.W, fs.bias, b["rel"], _C.LABEL_I64, b["n"], fs.go, B, L, F,
-                             fs.lossv, fs.part)
+                    allreduce_impl = ("ltr_linear_step_f32 + %s handle: ncclAllReduce %s (RCCL communicator of its own)" % (
+                        ("in-stream", "on the step's stream behind its kernels") if mode == "instream" else
+                        ("overlap", "on a side stream under the next step")))
+
+                def step(i):
+                    b = batches[i % nbuf]
+                    if mode in ("instream", "mailbox"):      # synchronous SGD: kernels, all-reduce, W -= lr * dW -- one C-ABI call
+                        raw.sgd_step(fs.kind_id, 1.0, b["X"], fs.W, fs.bias, b["rel"], _C.LABEL_I64, b["n"], fs.go, B, L, F,
+                                     SGD_LR, fs.lossv, fs.part)
+                    else:
+                        raw.step(i, fs.kind_id, 1.0, b["X"], fs.W, fs.bias, b["rel"], _C.LABEL_I64, b["n"], fs.go, B, L, F,
+                                 fs.lossv, fs.part)
         else:
             if raw is not None:
                 sys.stderr.write("[bench] raw RCCL communicator unavailable (%s): torch.distributed all_reduce\n" % raw.why)
+                fell_back.append("raw RCCL communicator unavailable (%s)" % raw.why)
                 raw.close()
+            mode = "c10d"
             red = OverlappedBucketAllReduce(F, count=B, device=dev, depth=1)
             allreduce_impl = "torch.distributed all_reduce per step (blocking)"
 
@@ -851,11 +988,13 @@ def main():
             if j == accum - 1:
                 dist.all_reduce(ar_view, op=dist.ReduceOp.SUM)
 
+    note("warm-up")
     for i in range(max(args.warmup, 2 * nbuf)):
         step(i)
     if finish is not None:
         finish()
     torch.cuda.synchronize()
+    note("estimating the step")
     # enough steps for a >= 50 ms timed region (aim at 60), a multiple of the all-reduce period
     est_steps = 25 * accum
     ests = []
@@ -875,13 +1014,60 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         steps_timed = int(t.item())
     steps_timed = ((steps_timed + accum - 1) // accum) * accum
+    note("timing %d steps x 5" % steps_timed)
     regions = time_region(step, steps_timed, barrier, repeats=5, reduce_max=reduce_max, finish=finish)
+    note("timed")
+    elapsed = median(regions)
+    value = n_gpus * B * steps_timed / elapsed
+
+    # N > 1: every rank must hold the same weights after the same steps (synchronous SGD), and the other ways of carrying the
+    # step's all-reduce are timed next to the headline's -- the mailbox step as three launches and the in-stream ncclAllReduce
+    # (RCCL over xGMI: north_star's wording) -- so that one hardware run yields them all
+    dp_extra = None
+    if dist is not None and accum == 1:
+        dp_extra = {"allreduce_mode": mode, "fell_back": fell_back}
+        torch.cuda.synchronize()
+        wb = [None] * n_gpus
+        dist.all_gather_object(wb, torch.cat([fs.W, fs.bias]).cpu().numpy().tobytes())
+        dp_extra["weights_bit_identical_across_ranks"] = all(x == wb[0] for x in wb)
+        dp_extra["device_status"] = int(fs.lib.ltr_device_status(0))
+        nalt = max(20, steps_timed // 4)
+
+        def time_alt(fn, fin=None):
+            for i in range(2 * nbuf):
+                fn(i)
+            if fin is not None:
+                fin()
+            r = time_region(fn, nalt, barrier, repeats=3, reduce_max=reduce_max, finish=fin)
+            return median(r) / nalt * 1e6
+        if mode == "lazy":
+            dp_extra["lazy_one_launch_step_us"] = elapsed / steps_timed * 1e6
+
+            def mstep(i):
+                b = batches[i % nbuf]
+                red.sgd_step(fs.kind_id, 1.0, b["X"], fs.W, fs.bias, b["rel"], _C.LABEL_I64, b["n"], fs.go, B, L, F, SGD_LR, fs.lossv, fs.part)
+            dp_extra["mailbox_three_launch_step_us"] = time_alt(mstep)
+        if mode != "instream" and backend == "nccl" and n_gpus > 1:
+            rc_ = RcclOverlap(F, count=B, device=dev, depth=0)
+            if rc_.ok:
+                def rstep(i):
+                    b = batches[i % nbuf]
+                    rc_.sgd_step(fs.kind_id, 1.0, b["X"], fs.W, fs.bias, b["rel"], _C.LABEL_I64, b["n"], fs.go, B, L, F, SGD_LR, fs.lossv, fs.part)
+                dp_extra["rccl_instream_step_us"] = time_alt(rstep)
+                dp_extra["rccl_instream_what"] = ("ltr_linear_sgd_step_f32 + in-stream RCCL handle: kernel, reduction, ncclAllReduce on the "
+                                                  "step's stream, update (4 launches)")
+                rc_.flush()
+            else:
+                dp_extra["rccl_instream_step_us"] = None
+                dp_extra["rccl_instream_what"] = "raw RCCL communicator unavailable: %s" % rc_.why
+            rc_.close()
+        elif mode == "instream":
+            dp_extra["rccl_instream_step_us"] = elapsed / steps_timed * 1e6
     if red is not None:
         red.flush()
         if hasattr(red, "close"):
             red.close()
-    elapsed = median(regions)
-    value = n_gpus * B * steps_timed / elapsed
+        fs.mailbox = None
 
     # N > 1, headline mode: the gradient-accumulation variant (one all-reduce per 8 steps) next to it
     accum8 = None
@@ -922,44 +1108,6 @@ def main():
                   "what": "ltr_linear_sgd_step_f32: the same steps as two launches each (kernel; reduction + update) -- the "
                           "headline of rounds 4-5; same weights bit for bit"}
 
-    # the persistent multi-batch launch of SURVEY.md 8(d): the SAME steps (same rotating batches, same SGD update) as K-step
-    # launches of ltr_linear_sgd_steps_f32 -- one workgroup per query position resident over the batches, the reduction and
-    # the update done in-kernel, the next tile streaming under them (csrc/ltr_steps.inc; EXPERIMENTS.md round 5)
-    persistent = None
-    if dist is None:
-        try:
-            import ctypes
-            lib = fs.lib
-            plan = int(lib.ltr_linear_sgd_steps_plan(fs.kind_id, B, L, F))
-            Kp = 256
-            Parr = ctypes.c_void_p * Kp
-            xp = Parr(*[batches[k % nbuf]["X"].data_ptr() for k in range(Kp)])
-            rp = Parr(*[batches[k % nbuf]["rel"].data_ptr() for k in range(Kp)])
-            npp = Parr(*[batches[k % nbuf]["n"].data_ptr() for k in range(Kp)])
-            p_loss = torch.empty(Kp, B, device=dev)
-            p_bucket = torch.empty(Kp, F + 2, device=dev)
-            Wp, bp = fs.W.clone(), fs.bias.clone()
-
-            def pstep(i):
-                rc = lib.ltr_linear_sgd_steps_f32(fs.kind_id, 1.0, Kp, xp, rp, fs._C.LABEL_I64, npp, B, L, F, SGD_LR, Wp.data_ptr(),
-                                                  bp.data_ptr(), p_loss.data_ptr(), p_bucket.data_ptr(), fs.part.data_ptr(),
-                                                  fs.ws_bytes, fs._stream())
-                if rc:
-                    fs._C.check(rc)
-            for i in range(2):
-                pstep(i)
-            nl = max(2, steps_timed // Kp)
-            rps = time_region(pstep, nl, barrier, repeats=5, reduce_max=reduce_max)
-            tp = median(rps) / (nl * Kp)
-            persistent = {"entry_point": "ltr_linear_sgd_steps_f32", "plan_persistent_kernel": plan, "steps_per_launch": Kp,
-                          "launches_timed": nl, "us_per_step": tp * 1e6, "queries_per_s": B / tp,
-                          "per_step_call_us": elapsed / steps_timed * 1e6,
-                          "step_level_frac_of_hbm_peak": None,
-                          "what": "the same synchronous-SGD steps over the same rotating batches in K-step persistent launches "
-                                  "(in-kernel reduction + update, next tile streams under them); `value` stays the per-step call"}
-        except Exception as exc:  # pragma: no cover
-            persistent = {"error": repr(exc)[:200]}
-
     out = None
     if rank == 0:
         extra = {"timed_regions_s": regions, "steps_per_region": steps_timed}
@@ -967,13 +1115,16 @@ def main():
             extra["step_without_weight_update"] = noupd
         if eager2 is not None:
             extra["two_launch_step"] = eager2
-        if persistent is not None:
-            extra["persistent_multi_batch"] = persistent
         _ = pmc_record(args.workload)
         extra["pmc_counters"] = ("profiles/pmc_<workload>.json (separate rocprofv3 --pmc passes); refused when the kernel "
                                  "sources changed since: stale for %s" % (sorted(PMC_STALE) or "none"))
         if accum8 is not None:
             extra["gradient_accumulation_8"] = accum8
+        if dp_extra is not None:
+            extra["data_parallel"] = dp_extra
+            for k_ in ("rccl_instream_step_us", "mailbox_three_launch_step_us", "lazy_one_launch_step_us"):
+                if k_ in dp_extra:
+                    extra[k_] = dp_extra[k_]
         # ---- roofline of the dominant kernel: fused scorer+loss, cold, timed live with HIP events ----
         k_us, graphed = time_launches(lambda i: fs.kernel(batches[i % nbuf]), nbuf)
         k_evt = time_events(lambda i: fs.kernel(batches[i % nbuf]), 100)
@@ -1020,8 +1171,6 @@ def main():
         roofline["step_level"] = {"us_per_step": step_s * 1e6, "frac": moved / step_s / 1e9 / HBM_PEAK_GBS,
                                   "note": "must-move bytes / whole-step time / 8 TB/s (the per-kernel frac leaves the reduction "
                                           "launch and the launch boundaries out)"}
-        if persistent is not None and "us_per_step" in persistent:
-            persistent["step_level_frac_of_hbm_peak"] = moved / (persistent["us_per_step"] * 1e-6) / 1e9 / HBM_PEAK_GBS
         # what ONE ROUND of workgroups can stream at this batch size: the same grid, workgroup size and
         # ragged spans with nothing behind the loads (ltr_debug_stream_probe_f32)
         if fs.plan == "linear_regtile_kernel" and L * (F // 4) <= 19 * 512 and F % 4 == 0:
@@ -1074,13 +1223,18 @@ def main():
                                    "list_len=%d, n~U[1,%d]%s" % (args.workload, F, kind, B, L, L,
                                                                 " (full lists)" if args.full_lists else ""),
                        "global_batch": n_gpus * B, "list_len": L, "features": F, "loss": kind,
-                       "mode": "eager", "parallelism": "dp%d" % n_gpus,
+                       "mode": "eager", "parallelism": "dp%d" % n_gpus, "devices": devices,
                        "step": (("synchronous SGD step in one C-ABI call AND ONE LAUNCH (ltr_linear_sgd_lazy_step_f32): fused scorer + "
                                  "loss kernel whose first workgroups sum the PREVIOUS step's per-query gradient rows into [dW | db | "
                                  "loss_sum], apply W -= lr * dW (lr %g) and hand the new weights to every workgroup before the dot "
                                  "products; each timed region ends with ltr_linear_sgd_flush_f32 (the last step's update): as many "
                                  "updates as steps, weights bit-identical to the two-launch step (extra.two_launch_step) -- "
                                  "examples/01-basic-usage.py:66-75" % SGD_LR) if lazy_headline else
+                                ("data-parallel synchronous SGD step in one C-ABI call AND ONE LAUNCH per rank "
+                                 "(ltr_linear_sgd_lazy_step_dp_f32): as at N = 1, and the reducer workgroups all-reduce their column "
+                                 "sums over the ranks inside the launch (lr %g); each timed region ends with "
+                                 "ltr_linear_sgd_flush_dp_f32 -- examples/01-basic-usage.py:66-75, sharded" % SGD_LR)
+                                if (dist is not None and accum == 1 and mode == "lazy") else
                                 ("synchronous SGD step in one C-ABI call (ltr_linear_sgd_step_f32): fused scorer + loss "
                                 "kernel, cross-query reduction into [dW | db | loss_sum]%s, W -= lr * dW (lr %g) -- "
                                 "examples/01-basic-usage.py:66-75" % (

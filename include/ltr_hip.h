@@ -404,29 +404,6 @@ int ltr_linear_sgd_step_f32(int kind, float sigma, const float *X, float *W, flo
                             int rel_dtype, const int64_t *n, const float *grad_out, int B, int L, int F,
                             float lr, float *loss, float *bucket /* F + 2 */, void *workspace,
                             size_t workspace_bytes, void *overlap /* or NULL */, void *stream);
-/* K synchronous-SGD steps over K batches in ONE persistent launch ("a persistent multi-batch
- * launch"): exactly the K calls
- *     for k in range(K): ltr_linear_sgd_step_f32(kind, sigma, X[k], W, bias, rel[k], rel_dtype, n[k], NULL (= 1/B), B, L, F,
- *                                                lr, loss + k*B, bucket + k*(F+2), ...)
- * of the reference's loop body (examples/01-basic-usage.py:66-75, `.mean().backward()` + SGD), but one workgroup per
- * query position stays resident over all K batches: the tile of batch k + 1 streams from HBM while the gradient of
- * batch k is summed over the queries and the weights are updated (by the workgroups themselves: tagged 16-byte
- * write-through units, no launch boundary, fixed summation order -- results are deterministic run to run and equal
- * the per-step path's up to fp32 summation order).  X / rel / n are HOST arrays of K DEVICE pointers (every batch
- * B x L x F, row-major, resident; the DataLoader knows the next batches).  loss: K * B per-query losses; bucket:
- * K * (F + 2) floats, per step the mean gradient dW | db and the sum of the losses.  W / bias are read at entry and
- * hold the weights after the last step on return (stream order).  Shapes the persistent kernel does not take
- * (ltr_linear_sgd_steps_plan == 0: rows not whole float4, lists over 256 documents or too long for nine register
- * sweeps, more queries than can be resident at once -- 4 workgroups per CU --, fewer queries than 2 (F + 4) / 3,
- * the LambdaNDCG kinds, a stream under capture) run as the K per-step calls, for which `workspace` must hold
- * ltr_linear_workspace_bytes(B, L, F).  A wait inside the launch that gives up (a workgroup not resident for
- * seconds) raises LTR_ERR_TIMEOUT in the device status and W / bias are NOT written. */
-int ltr_linear_sgd_steps_f32(int kind, float sigma, int K, const float *const *X, const void *const *rel, int rel_dtype,
-                             const int64_t *const *n, int B, int L, int F, float lr, float *W, float *bias,
-                             float *loss /* K * B */, float *bucket /* K * (F + 2) */, void *workspace,
-                             size_t workspace_bytes, void *stream);
-/* 1 when ltr_linear_sgd_steps_f32 takes this shape on the persistent kernel, 0 when it runs K per-step calls. */
-int ltr_linear_sgd_steps_plan(int kind, int B, int L, int F);
 /* The same step with the update applied LAZILY (examples/01-basic-usage.py:66-75, one batch per call as the DataLoader hands
  * them over): the call computes this batch's per-query gradient rows into `workspace` and its losses into `loss`, and applies
  * the update of the PREVIOUS call's batch first -- pending_B (> 0) = the number of queries of that batch, whose rows and losses
@@ -448,11 +425,30 @@ int ltr_linear_sgd_lazy_step_f32(int kind, float sigma, const float *X, float *W
  * (kind, pending_B, L, F); 0: nothing to do), bucket = [dW | db | loss_sum]: the reduction launch of ltr_linear_sgd_step_f32. */
 int ltr_linear_sgd_flush_f32(int kind, float *W, float *bias, int pending_B, int L, int F, float lr, const float *loss,
                              float *bucket /* F + 2 */, const void *workspace, void *stream);
-/* Tests only: != 0 makes every wait of the persistent kernel give up at once. */
-LTR_DEBUG_HOOK void ltr_debug_steps_force_timeout(int on);
-/* Tuning only: a device buffer of K * B * 8 int64 that later ltr_linear_sgd_steps_f32 launches fill with 100 MHz
- * wall-clock stamps per step and workgroup (scripts/dev/trace_steps.py), or NULL to stop. */
-LTR_DEBUG_HOOK void ltr_debug_steps_trace(long long *buffer);
+/* The lazy step, DATA PARALLEL (one process per GPU, the queries of a global batch sharded over the ranks; the reference's loop
+ * body examples/01-basic-usage.py:66-75 is single-process -- this is its synchronous data-parallel form): the same ONE launch per
+ * step at every number of ranks.  `mailbox` is a connected ltr_mailbox_* handle created with count_max >= F + 2 (NULL, or a
+ * one-rank mailbox: exactly ltr_linear_sgd_lazy_step_f32); pending_scale the weight of every pending query's gradient row --
+ * 1 / (queries of the pending GLOBAL batch) makes the update the gradient of the global mean (<= 0: 1 / pending_B).  The reducer
+ * workgroups in front of the launch sum this rank's rows of the pending batch, post {tag, sum} of their columns to every
+ * peer's mailbox (its lazy half: the plain ltr_mailbox_allreduce calls are not disturbed), add what arrives IN RANK ORDER, and
+ * publish the new weights to the launch; ONE workgroup (the losses' reducer) writes W / bias once every column has arrived -- all ranks
+ * hold bit-identical weights after every step, and a peer that never shows up (ltr_mailbox_set_timeout_ms) leaves W / bias
+ * untouched AS A WHOLE and raises LTR_ERR_TIMEOUT in the device status.  bucket = [dW | db | loss_sum] summed over the ranks.
+ * Every rank makes the same sequence of calls with B > 0; eager launches only (a stream under capture: LTR_ERR_CONFIG when an
+ * update is pending).  Shapes the launch does not take along flush first (below).  One process per GPU: a launch's reducers wait
+ * for the peers' reducers INSIDE the kernel, so the ranks' launches must be resident at the same time -- ranks that share one
+ * device (functional tests) must fit it together, B + (F + 4) / 4 + 1 workgroups each at four per CU. */
+int ltr_linear_sgd_lazy_step_dp_f32(int kind, float sigma, const float *X, float *W, float *bias, const void *rel,
+                                    int rel_dtype, const int64_t *n, int B, int L, int F, float lr, float *loss,
+                                    float *bucket /* F + 2 */, void *workspace, size_t workspace_bytes, int pending_B,
+                                    float pending_scale, void *mailbox /* or NULL */, void *stream);
+/* ltr_linear_sgd_flush_f32, data parallel: the pending batch's update with its all-reduce in ONE launch (the reducers on their
+ * own; rows by query -- shapes off the register tile --: the reduction launch and the
+ * plain mailbox all-reduce with the update riding in it). */
+int ltr_linear_sgd_flush_dp_f32(int kind, float *W, float *bias, int pending_B, int L, int F, float lr, float pending_scale,
+                                const float *loss, float *bucket /* F + 2 */, const void *workspace,
+                                void *mailbox /* or NULL */, void *stream);
 /* Mailbox all-reduce: the < 3 KB gradient bucket of a data-parallel step summed over the ranks of ONE node by a
  * single small kernel per rank instead of a collective library (one process per GPU; no counterpart in the
  * reference, which is single-process).  Every rank owns a mailbox of 8-byte {tag, value} granules in fine-grained

@@ -11,14 +11,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libltr_hip.so")
-# four translation units, compiled side by side and linked into one library: the loss / metric /
-# helper kernels with the C ABI, the fused Linear scorer + loss kernels, the fused MLP + scorer layer,
-# the persistent multi-batch training kernel
-SOURCES = [os.path.join(CSRC, f) for f in ("ltr_kernels.hip", "ltr_linear.hip", "ltr_mlp.hip", "ltr_steps.hip")]
-# per-source compiler flags.  ltr_steps.hip: the step loop of the persistent kernel is one big loop body; machine LICM
-# hoists the pair pass's materialised constants and addresses out of it and keeps them in VGPRs next to the register
-# tile (32 spilled VGPRs under the 64 of four workgroups per CU; none without the pass)
-SOURCE_FLAGS = {"ltr_steps.hip": ["-mllvm", "-disable-machine-licm"]}
+# three translation units, compiled side by side and linked into one library: the loss / metric /
+# helper kernels with the C ABI, the fused Linear scorer + loss kernels, the fused MLP + scorer layer
+SOURCES = [os.path.join(CSRC, f) for f in ("ltr_kernels.hip", "ltr_linear.hip", "ltr_mlp.hip")]
+SOURCE_FLAGS = {}          # per-source compiler flags (none at present)
 OBJ_DIR = os.path.join(_ROOT, "build", "obj")
 # every .inc the translation units include, and the public header
 DEPENDS = SOURCES + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".inc")) + \

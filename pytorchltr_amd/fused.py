@@ -274,60 +274,6 @@ def linear_loss_step(xs, weight, bias, relevance, n, loss="hinge", grad_out=None
     return out
 
 
-def linear_sgd_steps(batches, weight, bias, lr, loss="hinge", return_losses=False):
-    """K synchronous-SGD steps of the reference's training loop body in ONE persistent launch
-    (include/ltr_hip.h: ltr_linear_sgd_steps_f32; examples/01-basic-usage.py:66-75):
-
-        for xs, ys, n in batches:                      # every batch (B, L, F) / (B, L) / (B,), resident on the device
-            loss = loss_fn(Linear(F, 1)(xs), ys, n).mean(); loss.backward(); SGD.step()
-
-    `weight` (F elements) and `bias` (1 element or None) are updated IN PLACE (fp32, contiguous).  Returns
-    (mean_loss[K], grads[K, F + 1]) -- per step the mean loss and the mean gradient dW | db it applied -- and the
-    per-query losses [K, B] with return_losses.  The batch of step k + 1 streams from HBM while step k's gradient is
-    reduced and the weights are updated; shapes the persistent kernel does not take run as K per-step calls (same
-    results up to fp32 summation order)."""
-    kind, sigma = _resolve_loss(loss)
-    batches = list(batches)
-    K = len(batches)
-    if K == 0:
-        raise ValueError("no batches")
-    Xs, rs, ns = [], [], []
-    B = L = F = None
-    for xs, ys, n in batches:
-        X = _prepare_features(xs)
-        if B is None:
-            B, L, F = X.shape
-        elif tuple(X.shape) != (B, L, F):
-            raise ValueError("every batch must have the same shape (the persistent launch keeps one workgroup per query position)")
-        r, nn = _labels_and_n(ys, n, B, L, X.device)
-        if rs and r.dtype != rs[0].dtype:
-            raise ValueError("every batch must use the same label dtype")
-        Xs.append(X); rs.append(r); ns.append(nn)
-    dev = Xs[0].device
-    if weight.dtype is not torch.float32 or not weight.is_contiguous() or weight.numel() != F or not weight.is_cuda:
-        raise ValueError("weight must be a contiguous fp32 device tensor of %d elements (it is updated in place)" % F)
-    if bias is not None and (bias.dtype is not torch.float32 or bias.numel() != 1 or not bias.is_cuda):
-        raise ValueError("bias must be an fp32 device tensor of one element (it is updated in place)")
-    lossv = torch.empty(K, B, dtype=torch.float32, device=dev)
-    bucket = torch.empty(K, F + 2, dtype=torch.float32, device=dev)
-    ws_bytes = _C.lib().ltr_linear_workspace_bytes(B, L, F)
-    ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=dev)
-    PtrArr = ctypes.c_void_p * K
-    xp = PtrArr(*[t.data_ptr() for t in Xs])
-    rp = PtrArr(*[t.data_ptr() for t in rs])
-    np_ = PtrArr(*[t.data_ptr() for t in ns])
-    with _C.device_ctx(Xs[0]):
-        _C.check(_C.lib().ltr_linear_sgd_steps_f32(
-            kind, float(sigma), K, xp, rp, _C.label_dtype(rs[0]), np_, B, L, F, float(lr),
-            weight.data_ptr(), None if bias is None else bias.data_ptr(), lossv.data_ptr(), bucket.data_ptr(),
-            ws.data_ptr(), ws.numel() * 4, _C.stream_of(Xs[0])))
-    # (the launch reads the batches asynchronously: keep them alive until the stream has passed it)
-    for t in Xs + rs + ns:
-        t.record_stream(torch.cuda.current_stream(dev))
-    out = (bucket[:, F + 1] / float(B), bucket[:, :F + 1])
-    return out + (lossv,) if return_losses else out
-
-
 class LazySGD:
     """The reference's training loop body, one batch per call as the DataLoader hands them over, with the optimiser
     step applied LAZILY (include/ltr_hip.h: ltr_linear_sgd_lazy_step_f32; examples/01-basic-usage.py:66-75):
@@ -341,15 +287,26 @@ class LazySGD:
     update inside the same launch (its first workgroups sum that batch's rows and hand the new weights to every
     workgroup before the dot products), so the reduction launch and a kernel boundary per step are gone.  Weights,
     gradients and losses are bit-identical to the eager step's.  `weight` (F elements) / `bias` (one element) are
-    contiguous fp32 device tensors, updated in place; every batch must have the same (B, L, F)."""
+    contiguous fp32 device tensors, updated in place; every batch must have the same (B, L, F).
 
-    def __init__(self, weight, bias, lr, loss="hinge"):
+    Data parallel (one process per GPU, every rank steps through its shard of each global batch):
+    ``LazySGD(weight, bias, lr, loss, mailbox=MailboxOverlap(F, count=B_shard, device=dev))`` -- the step stays ONE launch
+    per rank: the reducer workgroups all-reduce their column sums through the peers' mailboxes inside the launch
+    (include/ltr_hip.h: ltr_linear_sgd_lazy_step_dp_f32); all ranks hold bit-identical weights after every step and
+    the update is the gradient of the mean over the GLOBAL batch (`mailbox.global_count` queries)."""
+
+    def __init__(self, weight, bias, lr, loss="hinge", mailbox=None):
         self.kind, self.sigma = _resolve_loss(loss)
         if weight.dtype is not torch.float32 or not weight.is_contiguous() or not weight.is_cuda:
             raise ValueError("weight must be a contiguous fp32 device tensor (it is updated in place)")
         if bias is None or bias.dtype is not torch.float32 or bias.numel() != 1 or not bias.is_cuda:
             raise ValueError("bias must be an fp32 device tensor of one element (it is updated in place)")
         self.weight, self.bias, self.lr = weight, bias, float(lr)
+        if mailbox is not None and not getattr(mailbox, "ok", False):
+            raise ValueError("the mailbox is not usable (%s): take RcclOverlap.sgd_step instead" % getattr(mailbox, "why", "?"))
+        self.mailbox = mailbox
+        self._mb = None if mailbox is None else mailbox.mbox
+        self._scale = 0.0 if mailbox is None else 1.0 / float(mailbox.global_count)
         self.pending = 0
         self.shape = None
         self.loss = self.bucket = self.ws = None
@@ -370,10 +327,10 @@ class LazySGD:
             raise ValueError("every batch must have the shape of the first one %r (flush() and make a new LazySGD otherwise)" % (self.shape,))
         r, nn = _labels_and_n(relevance, n, B, L, X.device)
         with _C.device_ctx(X):
-            _C.check(_C.lib().ltr_linear_sgd_lazy_step_f32(
+            _C.check(_C.lib().ltr_linear_sgd_lazy_step_dp_f32(
                 self.kind, float(self.sigma), _C.ptr(X), self.weight.data_ptr(), self.bias.data_ptr(), _C.ptr(r),
                 _C.label_dtype(r), _C.ptr(nn), B, L, F, self.lr, self.loss.data_ptr(), self.bucket.data_ptr(),
-                self.ws.data_ptr(), self.ws.numel() * 4, self.pending, _C.stream_of(X)))
+                self.ws.data_ptr(), self.ws.numel() * 4, self.pending, self._scale, self._mb, _C.stream_of(X)))
         for t in (X, r, nn):
             t.record_stream(torch.cuda.current_stream(X.device))
         self.pending = B
@@ -383,14 +340,15 @@ class LazySGD:
         if self.pending:
             B, L, F = self.shape
             with _C.device_ctx(self.ws):
-                _C.check(_C.lib().ltr_linear_sgd_flush_f32(
-                    self.kind, self.weight.data_ptr(), self.bias.data_ptr(), self.pending, L, F, self.lr,
-                    self.loss.data_ptr(), self.bucket.data_ptr(), self.ws.data_ptr(), _C.stream_of(self.ws)))
+                _C.check(_C.lib().ltr_linear_sgd_flush_dp_f32(
+                    self.kind, self.weight.data_ptr(), self.bias.data_ptr(), self.pending, L, F, self.lr, self._scale,
+                    self.loss.data_ptr(), self.bucket.data_ptr(), self.ws.data_ptr(), self._mb, _C.stream_of(self.ws)))
             self.pending = 0
         if self.bucket is None:
             return None
         F = self.shape[2]
-        return self.bucket[F + 1] / float(self.shape[0]), self.bucket[:F + 1]
+        count = float(self.shape[0]) if self.mailbox is None else float(self.mailbox.global_count)
+        return self.bucket[F + 1] / count, self.bucket[:F + 1]
 
 
 # ---------------------------------------------------------------------------------------------

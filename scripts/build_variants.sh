@@ -10,7 +10,7 @@ C="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -
 for spec in "$@"; do
   name="${spec%%:*}"; flags="${spec#*:}"
   ( $C $flags -c pytorchltr_amd/csrc/ltr_linear.hip -o build/variants/ltr_linear_$name.o &&
-    $C -shared -o build/variants/libltr_$name.so build/obj/ltr_kernels.o build/variants/ltr_linear_$name.o build/obj/ltr_mlp.o build/obj/ltr_steps.o ) &
+    $C -shared -o build/variants/libltr_$name.so build/obj/ltr_kernels.o build/variants/ltr_linear_$name.o build/obj/ltr_mlp.o ) &
 done
 wait
 ls -la build/variants/*.so

@@ -1,7 +1,7 @@
 """A/B of the fused scorer + loss kernel between library builds, cold rotation:
-python scripts/dev/lib_ab.py lib1.so lib2.so -- hinge:32x1000x220 dcg_hinge:256x1000x220 ..."""
+python scripts/lib_ab.py lib1.so lib2.so -- hinge:32x1000x220 dcg_hinge:256x1000x220 ..."""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
 from pytorchltr_amd import _C

@@ -105,3 +105,35 @@ def test_two_ranks_on_one_gpu_run_the_data_parallel_step_with_the_mailbox_allred
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2048
     assert "mailbox" in out["config"]["allreduce"], out["config"]["allreduce"]
     assert out["config"]["allreduce_every"] == 1 and out["value"] > 1e5
+
+
+def test_bare_gpus_2_starts_its_ranks_and_takes_the_one_launch_data_parallel_step():
+    """`bench.py --gpus 2` run BARE (no launcher, WORLD_SIZE unset) starts its two ranks itself -- here both
+    on cuda:0 over gloo -- and the line says n_gpus 2 with the devices; the step is the data-parallel LAZY one (one launch per
+    rank, the all-reduce inside it), the ranks' weights are bit-identical, and the three-launch mailbox step is timed next to it.
+    (--workload c2s --shard: two ranks' grids of 256 + 37 workgroups are resident on the one GPU side by side; two C2 grids are
+    not, and a launch whose reducers wait for a peer whose launch cannot become resident never ends -- bench.py then takes the
+    three-launch mailbox step, which the weak-scaling test above exercises.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update({"LTR_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c2s", "--shard", "--steps", "20",
+                         "--warmup", "5", "--no-cpu-baseline", "--no-extra"], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                        timeout=600)
+    assert pr.returncode == 0, pr.stderr.decode()[-3000:]
+    lines = [ln for ln in pr.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and len(out["config"]["devices"]) == 2 and out["scaling"] == "strong"
+    dp = out["extra"]["data_parallel"]
+    assert dp["weights_bit_identical_across_ranks"] and dp["device_status"] == 0, dp
+    assert dp["allreduce_mode"] == "lazy", dp
+    assert "ltr_linear_sgd_lazy_step_dp_f32" in out["config"]["allreduce"]
+    assert out["extra"]["mailbox_three_launch_step_us"] > 0
+
+
+def test_world_size_must_match_gpus():
+    env = dict(os.environ)
+    env.update({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "5", "--warmup", "1"], env=env,
+                        cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert pr.returncode != 0 and b"must agree" in pr.stderr
