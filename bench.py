@@ -298,12 +298,12 @@ class FusedStep:
             self.kind_id, 1.0, batch["X"].data_ptr(), self.W.data_ptr(), self.bias.data_ptr(),
             batch["rel"].data_ptr(), self._C.LABEL_I64, batch["n"].data_ptr(), self.B, self.L, self.F, float(lr),
             self.lossv.data_ptr(), self.flat.data_ptr(), self.part.data_ptr(), self.ws_bytes, self.pending,
-            self.lazy_scale, self.mailbox, self._stream()))
+            self.lazy_scale, None, 0, self.mailbox, self._stream()))
         self.pending = self.B
 
     def lazy_flush(self, lr=SGD_LR):
         self._C.check(self.lib.ltr_linear_sgd_flush_dp_f32(
-            self.kind_id, self.W.data_ptr(), self.bias.data_ptr(), self.pending, self.L, self.F, float(lr), self.lazy_scale,
+            self.kind_id, self.W.data_ptr(), self.bias.data_ptr(), self.pending, self.L, self.F, float(lr), self.lazy_scale, None, 0,
             self.lossv.data_ptr(), self.flat.data_ptr(), self.part.data_ptr(), self.mailbox, self._stream()))
         self.pending = 0
 
@@ -1346,6 +1346,36 @@ def n1_extras(args, kind, B, L, F, dev, batches, steps_timed):
         loss_fn(scorer(b0["X"]), b0["rel"], b0["n"]).mean().backward()
     extra["dropin_use_linear_scorer_plus_loss_module"] = measure(dropin_scorer_step)
 
+    # (b2') the reference's WHOLE loop body as the user writes it -- loss = loss_fn(model(xs), ys, n).mean(); optimizer.zero_grad();
+    # loss.backward(); optimizer.step() -- with the two changed lines: model = use_linear_scorer(model) and
+    # pytorchltr_amd.optim.SGD for torch.optim.SGD (one kernel launch per step for the scorer: the lazy step; + .mean() and its
+    # backward, which the user wrote), next to the same loop with torch.optim.SGD
+    try:
+        from pytorchltr_amd.optim import SGD as LazyOptSGD
+        for name_, make_opt in (("dropin_loop_lazy_sgd", lambda ps: LazyOptSGD(ps, lr=1e-6)),
+                                ("dropin_loop_torch_sgd", lambda ps: torch.optim.SGD(ps, lr=1e-6))):
+            m_ = use_linear_scorer(torch.nn.Linear(F, 1).to(dev))
+            o_ = make_opt(m_.parameters())
+
+            def loop_step():
+                bt = batches[loop_step.i % nbuf]
+                loop_step.i += 1
+                loss_ = loss_fn(m_(bt["X"]), bt["rel"], bt["n"]).mean()
+                o_.zero_grad()
+                loss_.backward()
+                o_.step()
+            loop_step.i = 0
+            for _ in range(20):
+                loop_step()
+            t_ = median(time_region(lambda i: loop_step(), reps, lambda: None, repeats=3)) / reps
+            extra[name_] = {"eager_us_per_step": t_ * 1e6, "eager_queries_per_s": B / t_,
+                            "what": "examples/01-basic-usage.py:70-75 verbatim, rotating cold batches, optimizer step included"}
+            if hasattr(o_, "flush"):
+                o_.flush()
+            del m_, o_
+    except Exception as exc:  # pragma: no cover
+        extra["dropin_loop_lazy_sgd"] = {"error": repr(exc)[:200]}
+
     # (b3) the whole training step of examples/01-basic-usage.py:66-75 as the user writes it -- model = use_linear_scorer(
     # nn.Linear(F, 1)), loss_fn(model(xs), ys, n).mean().backward(), torch.optim.SGD step -- captured ONCE by
     # pytorchltr_amd.GraphedStep and replayed per batch (the eager figures above vary 2x between
@@ -1355,7 +1385,8 @@ def n1_extras(args, kind, B, L, F, dev, batches, steps_timed):
         try:
             from pytorchltr_amd.graphed import GraphedStep
             gmodel = use_linear_scorer(torch.nn.Linear(F, 1).to(dev))
-            gopt = torch.optim.SGD(gmodel.parameters(), lr=1e-6)
+            from pytorchltr_amd.optim import SGD as LazyOptSGD_
+            gopt = LazyOptSGD_(gmodel.parameters(), lr=1e-6)
             gstep = GraphedStep(gmodel, gopt, lambda xs, ys, n_: loss_fn(gmodel(xs), ys, n_).mean(),
                                 example_batch=(b0["X"], b0["rel"], b0["n"]))
             for _ in range(20):
@@ -1366,8 +1397,9 @@ def n1_extras(args, kind, B, L, F, dev, batches, steps_timed):
             t_call = median(time_region(lambda i: gstep(batches[i % nbuf]["X"], batches[i % nbuf]["rel"], batches[i % nbuf]["n"]),
                                         max(50, reps // 4), lambda: None, repeats=3)) / max(50, reps // 4)
             extra["graphed_step_dropin_sgd"] = {
-                "what": "GraphedStep(use_linear_scorer(nn.Linear(F,1)), SGD, loss_fn(model(xs), ys, n).mean()): forward + backward + "
-                        "optimizer.step() replayed as one hipGraph",
+                "what": "GraphedStep(use_linear_scorer(nn.Linear(F,1)), pytorchltr_amd.optim.SGD, loss_fn(model(xs), ys, n).mean()): forward "
+                        "+ backward + optimizer.step() replayed as one hipGraph (the previous step's reduction + update, the fused kernel, "
+                        ".mean() and its backward)",
                 "replay_us_per_step": t_replay * 1e6, "replay_queries_per_s": B / t_replay,
                 "call_with_batch_copy_us_per_step": t_call * 1e6, "call_with_batch_copy_queries_per_s": B / t_call,
                 "batch_copy_bytes": int(b0["X"].numel() * 4 + b0["rel"].numel() * b0["rel"].element_size() + b0["n"].numel() * 8)}

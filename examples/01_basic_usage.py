@@ -41,13 +41,21 @@ def example3_path(split):
     return path
 
 
-def run(train_path=None, test_path=None, epochs=3, device="cuda", log=logging.info):
+def run(train_path=None, test_path=None, epochs=3, device="cuda", log=logging.info, fast=False):
+    """fast=True: the two lines that put the loop on the one-launch path -- `model = use_linear_scorer(model)` and
+    `pytorchltr_amd.optim.SGD` in place of `torch.optim.SGD`; the loop body is the reference's either way."""
     torch.manual_seed(42)
     # Example3(normalize=True) in the reference (example3.py:39)
     train = load_svmrank(train_path or example3_path("train"), normalize=True, device=device)
     test = load_svmrank(test_path or example3_path("test"), normalize=True, device=device)
     model = torch.nn.Linear(train.features.shape[1], 1).to(device)
-    optimizer = torch.optim.SGD(model.parameters(), lr=0.1)
+    if fast:
+        from pytorchltr_amd.fused import use_linear_scorer
+        from pytorchltr_amd.optim import SGD
+        model = use_linear_scorer(model)
+        optimizer = SGD(model.parameters(), lr=0.1)
+    else:
+        optimizer = torch.optim.SGD(model.parameters(), lr=0.1)
     loss_fn = PairwiseHingeLoss()
 
     def evaluate():

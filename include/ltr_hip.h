@@ -429,7 +429,10 @@ int ltr_linear_sgd_flush_f32(int kind, float *W, float *bias, int pending_B, int
  * body examples/01-basic-usage.py:66-75 is single-process -- this is its synchronous data-parallel form): the same ONE launch per
  * step at every number of ranks.  `mailbox` is a connected ltr_mailbox_* handle created with count_max >= F + 2 (NULL, or a
  * one-rank mailbox: exactly ltr_linear_sgd_lazy_step_f32); pending_scale the weight of every pending query's gradient row --
- * 1 / (queries of the pending GLOBAL batch) makes the update the gradient of the global mean (<= 0: 1 / pending_B).  The reducer
+ * 1 / (queries of the pending GLOBAL batch) makes the update the gradient of the global mean (<= 0: 1 / pending_B); with
+ * pending_scale_dev query b's weight is READ from pending_scale_dev[b * pending_scale_stride] by the launch that applies the update
+ * (the upstream gradient as autograd hands it over -- stride 0: `.sum()`'s expanded scalar, 1: `.mean()`'s vector of 1 / B or any
+ * per-query weights; pytorchltr_amd.optim.SGD).  The reducer
  * workgroups in front of the launch sum this rank's rows of the pending batch, post {tag, sum} of their columns to every
  * peer's mailbox (its lazy half: the plain ltr_mailbox_allreduce calls are not disturbed), add what arrives IN RANK ORDER, and
  * publish the new weights to the launch; ONE workgroup (the losses' reducer) writes W / bias once every column has arrived -- all ranks
@@ -442,13 +445,20 @@ int ltr_linear_sgd_flush_f32(int kind, float *W, float *bias, int pending_B, int
 int ltr_linear_sgd_lazy_step_dp_f32(int kind, float sigma, const float *X, float *W, float *bias, const void *rel,
                                     int rel_dtype, const int64_t *n, int B, int L, int F, float lr, float *loss,
                                     float *bucket /* F + 2 */, void *workspace, size_t workspace_bytes, int pending_B,
-                                    float pending_scale, void *mailbox /* or NULL */, void *stream);
+                                    float pending_scale, const float *pending_scale_dev /* or NULL */,
+                                    int pending_scale_stride, void *mailbox /* or NULL */, void *stream);
 /* ltr_linear_sgd_flush_f32, data parallel: the pending batch's update with its all-reduce in ONE launch (the reducers on their
  * own; rows by query -- shapes off the register tile --: the reduction launch and the
  * plain mailbox all-reduce with the update riding in it). */
 int ltr_linear_sgd_flush_dp_f32(int kind, float *W, float *bias, int pending_B, int L, int F, float lr, float pending_scale,
-                                const float *loss, float *bucket /* F + 2 */, const void *workspace,
-                                void *mailbox /* or NULL */, void *stream);
+                                const float *pending_scale_dev /* or NULL */, int pending_scale_stride, const float *loss,
+                                float *bucket /* F + 2 */, const void *workspace, void *mailbox /* or NULL */, void *stream);
+/* The reduction alone: bucket = [dW | db | loss_sum] of the batch whose rows a lazy step left in `workspace` (its layout follows
+ * from (kind, pending_B, L, F) and from whether the step had a bias), the weights untouched -- what reading `weight.grad` before
+ * the optimizer step costs in the drop-in path (torch.Tensor.grad of examples/01-basic-usage.py:73). */
+int ltr_linear_lazy_rows_reduce_f32(int kind, int pending_B, int L, int F, float pending_scale,
+                                    const float *pending_scale_dev /* or NULL */, int pending_scale_stride, const float *loss,
+                                    float *bucket /* F + 2 */, const void *workspace, int has_bias, void *stream);
 /* Mailbox all-reduce: the < 3 KB gradient bucket of a data-parallel step summed over the ranks of ONE node by a
  * single small kernel per rank instead of a collective library (one process per GPU; no counterpart in the
  * reference, which is single-process).  Every rank owns a mailbox of 8-byte {tag, value} granules in fine-grained

@@ -76,8 +76,9 @@ SIGNATURES = {
                                     _vp, _vp]),
     "ltr_linear_sgd_lazy_step_f32": (_i, [_i, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _sz, _i, _vp]),
     "ltr_linear_sgd_flush_f32": (_i, [_i, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
-    "ltr_linear_sgd_lazy_step_dp_f32": (_i, [_i, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _sz, _i, _f, _vp, _vp]),
-    "ltr_linear_sgd_flush_dp_f32": (_i, [_i, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "ltr_linear_sgd_lazy_step_dp_f32": (_i, [_i, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _sz, _i, _f, _vp, _i, _vp, _vp]),
+    "ltr_linear_sgd_flush_dp_f32": (_i, [_i, _vp, _vp, _i, _i, _i, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ltr_linear_lazy_rows_reduce_f32": (_i, [_i, _i, _i, _i, _f, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "ltr_debug_fake_allreduce": (_i, [_vp, _vp, _sz, _i, _i, _vp, _vp]),
     "ltr_mailbox_create": (_i, [_i, _i, _i, _vp, _vp]),
     "ltr_mailbox_connect": (_i, [_vp, _vp]),

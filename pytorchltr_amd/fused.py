@@ -125,9 +125,26 @@ class _LinearLossFunction(torch.autograd.Function):
         if weight.numel() != Fw:
             raise ValueError("weight has %d elements, features have %d" % (weight.numel(), Fw))
         dev = X.device
+        r, nn = _labels_and_n(relevance, n, B, L, dev)
+        # parameters that pytorchltr_amd.optim.SGD updates lazily: the lazy launch (this batch's rows + the previous
+        # step's update in ONE launch); its backward and the optimizer step then launch nothing
+        st = getattr(weight, "_ltr_lazy", None)
+        if st is not None:
+            if (not want_scores and bias is not None and Fw == F and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
+                    and getattr(bias, "_ltr_lazy", None) is st):
+                loss = st.forward(ctx, X, r, _LABEL_CODE[r.dtype], nn, kind, sigma)
+                if loss is not None:
+                    ctx.lazy_loss = loss.detach()            # (an alias without the autograd node: no reference cycle)
+                    ctx.save_for_backward(X, r, nn)
+                    ctx.lazy_args = (kind, sigma)
+                    ctx.dims = (B, F)
+                    ctx.Fw = Fw
+                    ctx.w_shape = weight.shape
+                    ctx.has_bias = True
+                    return loss
+            st.settle()                                      # the ordinary path reads the weights: no update may be pending
         W = _pad_weight(_flat_f32(weight, Fw), F)
         bvec = None if bias is None else _flat_f32(bias, 1)
-        r, nn = _labels_and_n(relevance, n, B, L, dev)
         loss = torch.empty(B, dtype=torch.float32, device=dev)
         # (B, PF) partials, then the kernel's scratch
         ws = torch.empty(_linear_ws_bytes(B, L, F) // 4, dtype=torch.float32, device=dev)
@@ -154,7 +171,28 @@ class _LinearLossFunction(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_loss, *unused):
-        (ws,) = ctx.saved_tensors
+        lz = getattr(ctx, "lazy", None)
+        if lz is not None:
+            st = lz[0]
+            out = st.backward(ctx, grad_loss)
+            if out is not None:
+                return (None, out[0], out[1], None, None, None, None, None)
+            # an upstream gradient that is not one broadcast scalar (per-query weights): the rows again, the ordinary way
+            # (the weights have not moved since the forward pass: no step can have been taken on this gradient)
+            if lz[1] != st.gen:
+                raise RuntimeError("the gradient rows of this forward pass are gone (a second backward pass through a "
+                                   "lazily updated scorer after later training steps)")
+            X, r, nn = ctx.saved_tensors
+            B, L, F = X.shape
+            kind, sigma = ctx.lazy_args
+            ws = torch.empty(_linear_ws_bytes(B, L, F) // 4, dtype=torch.float32, device=X.device)
+            scratch = torch.empty(B, dtype=torch.float32, device=X.device)
+            with _C.device_ctx(X):
+                _C.check(_C.lib().ltr_linear_partials_f32(
+                    kind, float(sigma), X.data_ptr(), st.w_raw.data_ptr(), st.b_raw.data_ptr(), r.data_ptr(),
+                    _LABEL_CODE[r.dtype], nn.data_ptr(), B, L, F, scratch.data_ptr(), None, ws.data_ptr(), _C.stream_of(X)))
+        else:
+            (ws,) = ctx.saved_tensors
         B, F = ctx.dims
         go = grad_loss
         dW = torch.empty(F, dtype=torch.float32, device=ws.device)
@@ -330,7 +368,7 @@ class LazySGD:
             _C.check(_C.lib().ltr_linear_sgd_lazy_step_dp_f32(
                 self.kind, float(self.sigma), _C.ptr(X), self.weight.data_ptr(), self.bias.data_ptr(), _C.ptr(r),
                 _C.label_dtype(r), _C.ptr(nn), B, L, F, self.lr, self.loss.data_ptr(), self.bucket.data_ptr(),
-                self.ws.data_ptr(), self.ws.numel() * 4, self.pending, self._scale, self._mb, _C.stream_of(X)))
+                self.ws.data_ptr(), self.ws.numel() * 4, self.pending, self._scale, None, 0, self._mb, _C.stream_of(X)))
         for t in (X, r, nn):
             t.record_stream(torch.cuda.current_stream(X.device))
         self.pending = B
@@ -341,7 +379,7 @@ class LazySGD:
             B, L, F = self.shape
             with _C.device_ctx(self.ws):
                 _C.check(_C.lib().ltr_linear_sgd_flush_dp_f32(
-                    self.kind, self.weight.data_ptr(), self.bias.data_ptr(), self.pending, L, F, self.lr, self._scale,
+                    self.kind, self.weight.data_ptr(), self.bias.data_ptr(), self.pending, L, F, self.lr, self._scale, None, 0,
                     self.loss.data_ptr(), self.bucket.data_ptr(), self.ws.data_ptr(), self._mb, _C.stream_of(self.ws)))
             self.pending = 0
         if self.bucket is None:
@@ -508,6 +546,7 @@ class LinearScorer(torch.nn.Module):
         if self.bias is not None:
             bound = 1.0 / math.sqrt(in_features)
             torch.nn.init.uniform_(self.bias, -bound, bound)
+            self.weight._ltr_scorer_bias = self.bias          # (pytorchltr_amd.optim.SGD pairs them up by this)
 
     def forward(self, xs, n=None):
         if not (torch.is_tensor(xs) and xs.dim() == 3 and xs.is_cuda and xs.dtype is torch.float32
@@ -536,6 +575,7 @@ def use_linear_scorer(model, predicate=None):
         sc.weight = lin.weight                      # the same Parameter objects
         if lin.bias is not None:
             sc.bias = lin.bias
+            sc.weight._ltr_scorer_bias = sc.bias
         return sc
 
     def is_scorer(m):

@@ -28,7 +28,7 @@ def _records():
 # kernels the BASELINE configs run on (plan table: tests/test_boundary.py; instantiations: csrc/*.inc launchers)
 BASELINE_KERNELS = [
     "linear_regtile2_kernel<0, 9, 34, 512>",        # C2  1024 x 128 x 136 hinge (the headline)
-    "linear_regtile2_kernel<6, 19, 34, 256>",       # C3  LambdaNDCG2
+    "linear_regtile2w_kernel<6, 19, 34, 256>",      # C3  LambdaNDCG2 (the uncapped entry point of the same body)
     "linear_cluster_kernel<1, 512, 8>",             # C4  256 x 1000 x 220 DCG-hinge (integer labels: sorted runs) and its shard of 8 GPUs (32 queries)
     "linear_cluster_kernel<1, 512, 12>",            # C4 on float labels (the pair pass)
     "linear_parts_kernel<0, 16, 3, 2, 0, false>",   # C5  512 x 512 x 700 hinge
@@ -64,8 +64,8 @@ def test_no_fused_scorer_kernel_outside_the_known_exceptions_spills():
     recs = _records()
     known = ("linear_parts_kernel<0, 40, 1, 2, 1, false>", "linear_parts_kernel<0, 20, 2, 2, 1, false>", "linear_parts_kernel<0, 14, 3, 2, 1, false>",
              "linear_parts_kernel<1, 40, 1, 2, 1, false>", "linear_parts_kernel<1, 20, 2, 2, 1, false>", "linear_parts_kernel<1, 14, 3, 2, 1, false>",
-             "linear_regtile_kernel<", "linear_regtile2_kernel<5, 24,", "linear_regtile2_kernel<6, 24,",
-             "linear_regtile2_kernel<2, 12, 0, 512>", "linear_regtile2_kernel<4, 12, 0, 512>",       # (one float4 each: see the ratchet below)       # (the NDCG kinds on 24 sweeps: 4-12 VGPRs, and faster than the two-pass kernel)
+             "linear_regtile_kernel<", "linear_regtile2w_kernel<5, 24,", "linear_regtile2w_kernel<6, 24,",
+             "linear_regtile2w_kernel<2, 12, 0, 512>", "linear_regtile2w_kernel<4, 12, 0, 512>",       # (one float4 each: see the ratchet below)       # (the NDCG kinds on 24 sweeps: 4-12 VGPRs, and faster than the two-pass kernel)
             
              "linear_cluster_kernel<5,", "linear_cluster_kernel<6,", "linear_cluster_kernel<2, 512, 12>",
              "linear_cluster_kernel<4, 512, 12>")
