@@ -1171,6 +1171,40 @@ def main():
         roofline["step_level"] = {"us_per_step": step_s * 1e6, "frac": moved / step_s / 1e9 / HBM_PEAK_GBS,
                                   "note": "must-move bytes / whole-step time / 8 TB/s (the per-kernel frac leaves the reduction "
                                           "launch and the launch boundaries out)"}
+        if lazy_headline and "plain_kernel" in roofline:
+            # ONE launch per step: the step's wall time bounds the launch's duration from above on every clock -- rocprofv3's
+            # kernel trace reads 0.3-0.4 us more per launch than the command processor's event pairs (profiles/README.md), so the
+            # headline fraction is taken on the clock that can only under-state it, and the event-pair figure is kept next to it
+            roofline["frac_event_pairs"] = roofline["frac"]
+            roofline["achieved_event_pairs"] = roofline["achieved"]
+            roofline["kernel_us_event_pairs"] = roofline["kernel_us_avg"]
+            roofline["kernel_us_avg"] = step_s * 1e6
+            roofline["achieved"] = moved / step_s / 1e9
+            roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
+            roofline["timing"] += ("; `kernel_us_avg` / `achieved` / `frac` are taken on the STEP's wall time (one launch per step: an "
+                                   "upper bound of the launch's duration on every clock, rocprofv3's included), the event-pair "
+                                   "figures are kernel_us_event_pairs / frac_event_pairs")
+        # the HBM rate this box reaches on a plain device copy (read + write of 1 GiB, hipMemcpy DtoD through torch), for scale
+        try:
+            src_ = torch.empty(256 * 2 ** 20, dtype=torch.float32, device=dev).normal_()
+            dst_ = torch.empty_like(src_)
+            for _ in range(3):
+                dst_.copy_(src_)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                dst_.copy_(src_)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 10 * 2 * src_.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            roofline["peak_measured"] = copy_gbs
+            roofline["frac_of_measured"] = roofline["achieved"] / copy_gbs
+            roofline["peak_measured_what"] = "device-to-device copy of 1 GiB (read + write bytes / time), this box, this run"
+            del src_, dst_
+            torch.cuda.empty_cache()
+        except Exception as exc:  # pragma: no cover
+            roofline["peak_measured"] = None
+            roofline["peak_measured_what"] = repr(exc)[:120]
         # what ONE ROUND of workgroups can stream at this batch size: the same grid, workgroup size and
         # ragged spans with nothing behind the loads (ltr_debug_stream_probe_f32)
         if fs.plan == "linear_regtile_kernel" and L * (F // 4) <= 19 * 512 and F % 4 == 0:

@@ -112,6 +112,21 @@ class ExtensionMissingError(ImportError):
     pass
 
 
+class _Library(ctypes.CDLL):
+    """ctypes.CDLL that says WHY a test / tuning hook is missing: a production build (LTR_NO_DEBUG_HOOKS=1) does not
+    export the ltr_debug_* entry points (the bare AttributeError came up far from its cause)."""
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            if name.startswith("ltr_debug_"):
+                raise AttributeError(
+                    "%s is a test / tuning hook and this libltr_hip.so was built without them (LTR_NO_DEBUG_HOOKS=1); "
+                    "rebuild with `python -m pytorchltr_amd.build --force` and the variable unset" % name) from None
+            raise
+
+
 def lib():
     """The loaded extension.  Raises loudly if it has not been built."""
     global _lib
@@ -121,7 +136,7 @@ def lib():
                 "pytorchltr_amd HIP extension not found at %s; build it with "
                 "`python -m pytorchltr_amd.build` (hipcc --offload-arch=gfx950). "
                 "There is no CPU fallback." % LIB_PATH)
-        handle = ctypes.CDLL(LIB_PATH)
+        handle = _Library(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
             if name.startswith("ltr_debug_") and not hasattr(handle, name):
                 continue                     # a production build (-DLTR_NO_DEBUG_HOOKS) leaves the test hooks out

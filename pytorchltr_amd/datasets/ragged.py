@@ -184,6 +184,7 @@ class RaggedQueries(_torch.utils.data.Dataset):
         qid = self._qids_host[idx].to(dev)
         if F != self.num_features:
             out_x = out_x[:, :, :self.num_features]          # the reference's (B, L, F) batch, rows F4 floats apart
+            out_x._ltr_zero_padded_rows = True               # (the hidden columns ARE zeros: what fused._padded_rows asks for)
         return SVMRankBatch(out_x, out_y, out_n, qid, False)
 
     def collate_fn(self, list_sampler: Optional[ListSampler] = None, sort_by_length: bool = False):

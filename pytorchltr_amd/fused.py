@@ -39,6 +39,11 @@ def _padded_rows(xs):
     columns meet zero weights, so any FINITE content is harmless (the collate writes zeros)."""
     if xs.dim() != 3 or xs.dtype is not torch.float32 or not xs.is_cuda:
         return None
+    # only batches the collate of this package made: there the hidden columns are zeros.  A user's own view with the same
+    # strides (big[..., :5] of an 8-column tensor) may hide NaN / Inf / metadata columns, which nn.Linear ignores and a
+    # zero weight does not (NaN * 0): those are copied to a contiguous batch like any other view (ADVICE r5)
+    if not getattr(xs, "_ltr_zero_padded_rows", False):
+        return None
     B, L, F = xs.shape
     F4 = (F + 3) & ~3
     if F4 == F or B == 0 or L == 0 or xs.stride(2) != 1 or xs.stride(1) != F4 or (B > 1 and xs.stride(0) != L * F4):
@@ -534,7 +539,14 @@ class LinearScorer(torch.nn.Module):
     module of this package then runs scores + loss + weight gradient as ONE kernel over the features (what
     ``FusedLinearLoss`` does), anything else that touches the scores computes them on the spot.  The feature batch gets
     no gradient (it is data); an input that requires one (the layer sits behind others) gets
-    ``grad_scores (x) weight``."""
+    ``grad_scores (x) weight``.
+
+    ONE difference from ``nn.Linear`` follows from the laziness: scores that are first USED after ``optimizer.step()`` --
+    ``scores = model(xs); loss_fn(scores, ys, n).mean().backward(); optimizer.step(); ndcg(scores, ys, n)`` -- would have to
+    be computed with weights that no longer exist; that first use raises a RuntimeError instead of returning post-step
+    scores.  Use the scores before the step (any use computes and keeps them), call ``scores.materialize()``, or build the
+    layer with ``lazy=False`` (``use_linear_scorer`` keeps the default) -- then every call computes its scores at once and
+    only the fused ``FusedLinearLoss`` / ``linear_loss_step`` entry points take the one-pass kernel."""
 
     def __init__(self, in_features, bias=True, lazy=True):
         super().__init__()

@@ -334,3 +334,13 @@ def test_rows_padded_to_whole_float4_take_the_vector_kernels(F):
         assert torch.allclose(m.bias.grad, lin.bias.grad, rtol=1e-4, atol=tol)
     with torch.no_grad():
         assert torch.allclose(model(bq.features), lin(bq.features), rtol=1e-5, atol=1e-5)
+    # a user's OWN view with the same strides hides whatever its tensor holds there -- NaN markers here -- and nn.Linear never
+    # sees those columns: such a view is copied, not taken for a zero-padded batch
+    big = torch.full((B, L, F4), float("nan"), device=dev)
+    big[:, :, :F] = bq.features
+    view = big[:, :, :F]
+    assert not getattr(view, "_ltr_zero_padded_rows", False)
+    loss2, dW2, db2 = linear_loss_step(view, W, b, bq.relevance, bq.n, loss="hinge")
+    assert torch.isfinite(loss2).all() and np.allclose(loss2.cpu().numpy(), want_l, rtol=2e-5, atol=1e-5)
+    with torch.no_grad():
+        assert torch.allclose(model(view), lin(view), rtol=1e-5, atol=1e-5)
