@@ -13,8 +13,41 @@ L, F = 128, 136
 rows = []
 for kind_name, kind in (("hinge", _C.HINGE), ("ndcg2", _C.NDCG2)):
     for full in (False, True):
-        for B in (256, 1024, 4096, 16384, 65536, 262144):
+        for B in (256, 1024, 4096, 16384, 65536, 262144, 1048576):
             g = torch.Generator().manual_seed(0)
+            if B > 262144:
+                # the loss-only and the metric kernels up to 2^20 queries (no feature tensor: 73 GB at this shape)
+                scores = torch.randn(B, L, generator=g).to(dev)
+                rel = torch.randint(0, 5, (B, L), generator=g).to(dev)
+                n = (torch.full((B,), L) if full else torch.randint(1, L + 1, (B,), generator=g)).to(dev)
+                loss = torch.empty(B, device=dev)
+                ds = torch.empty(B, L, device=dev)
+                cs = lambda: torch.cuda.current_stream().cuda_stream
+
+                def lossk():
+                    _C.check(lib.ltr_pairwise_loss_f32(kind, 1.0, scores.data_ptr(), rel.data_ptr(), 0, n.data_ptr(),
+                                                       B, L, loss.data_ptr(), ds.data_ptr(), cs()))
+
+                def ndcgk():
+                    _C.check(lib.ltr_dcg_f32(scores.data_ptr(), rel.data_ptr(), 0, n.data_ptr(), B, L, 10, 1, 1, loss.data_ptr(), cs()))
+
+                def arpk():
+                    _C.check(lib.ltr_arp_f32(scores.data_ptr(), rel.data_ptr(), 0, n.data_ptr(), B, L, loss.data_ptr(), cs()))
+                row = dict(kind=kind_name, full_lists=full, B=B)
+                for name, fn, alg in (("loss", lossk, B * (16 * L + 16)), ("ndcg10", ndcgk, B * (12 * L + 12)), ("arp", arpk, B * (12 * L + 12))):
+                    if name != "loss" and kind_name != "hinge":
+                        continue                      # (the metrics do not depend on the loss kind: once)
+                    for _ in range(2):
+                        fn()
+                    t, _ = time_launches(fn, per_graph=2, replays=3)
+                    row["%s_us" % name] = t
+                    row["%s_qps" % name] = B / t * 1e6
+                    row["%s_alg_GBs" % name] = alg / t / 1e3
+                rows.append(row)
+                print(json.dumps(row), flush=True)
+                del scores, rel, ds
+                torch.cuda.empty_cache()
+                continue
             scores = torch.randn(B, L, generator=g).to(dev)
             rel = torch.randint(0, 5, (B, L), generator=g).to(dev)
             n = (torch.full((B,), L) if full else torch.randint(1, L + 1, (B,), generator=g)).to(dev)

@@ -164,9 +164,8 @@ def test_sgd_step_refuses_a_deferred_allreduce():
 @pytest.mark.parametrize("shape", [("hinge", 1024, 128, 136), ("hinge", 300, 128, 136), ("ndcg2", 512, 128, 136),
                                    ("logistic", 257, 100, 220), ("dcg_hinge", 600, 60, 64), ("arp2", 96, 200, 136),
                                    ("hinge", 300, 10, 700), ("ndcg1", 1, 128, 136), ("hinge", 40, 1000, 220),
-                                   # more queries than one round of workgroups: the column-group rows, flushed by the reducers on
-                                   # their own in front of a plain launch
-                                   ("hinge", 2500, 64, 136), ("logistic", 5000, 40, 64)])
+                                   # more than 1024 pending queries: several reducer workgroups per column group, inside the launch
+                                   ("hinge", 2500, 64, 136), ("logistic", 5000, 40, 64), ("logistic", 4096, 100, 136)])
 def test_lazy_sgd_steps_are_the_eager_steps_bit_for_bit(shape):
     """ltr_linear_sgd_lazy_step_f32: step k + 1's launch applies step k's update itself (its first workgroups reduce the
     pending batch's partial rows in front of their tile burst and hand the new weights over as tagged granules), the last
@@ -225,10 +224,22 @@ def test_lazy_sgd_steps_are_the_eager_steps_bit_for_bit(shape):
 
     eager, lazy = run(False), run(True)
     assert set(eager) == set(lazy)
+    # beyond 1024 pending queries several reducer workgroups share a column group (round 6: a reducer never sums more than ~1024
+    # rows) and the last to arrive adds their partial sums in split order: another -- fixed -- summation order than the strided
+    # reduction launch's, so the same numbers to rounding, and the same BITS run after run
+    exact = B <= 1024
     for key in sorted(eager):
         for a, b2 in zip(eager[key], lazy[key]):
             assert np.all(np.isfinite(a)), key
-            assert np.array_equal(a, b2), key
+            if exact:
+                assert np.array_equal(a, b2), key
+            else:
+                assert np.allclose(a, b2, rtol=1e-4, atol=1e-5 * max(1.0, float(np.abs(a).max()))), (key, float(np.abs(a - b2).max()), float(np.abs(a).max()))
+    if not exact:
+        again = run(True)
+        for key in sorted(lazy):
+            for a, b2 in zip(lazy[key], again[key]):
+                assert np.array_equal(a, b2), key
 
 
 def test_lazy_sgd_module_trains_like_the_reference_loop():
