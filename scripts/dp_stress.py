@@ -24,7 +24,7 @@ def worker():
     lib = _C.lib()
     steps = int(os.environ["DP_STEPS"])
     L, F = 128, 136
-    for Bs in [int(x) for x in os.environ.get("DP_SHARDS", "64,256,448,512").split(",")]:
+    for Bs in [int(x) for x in os.environ.get("DP_SHARDS", "64,256,448").split(",")]:
         g = torch.Generator().manual_seed(100 + rank)
         nb = 4
         X = [torch.randn(Bs, L, F, generator=g).to(dev) for _ in range(nb)]
