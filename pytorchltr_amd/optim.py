@@ -117,7 +117,9 @@ _PARAM_NO_FLUSH = {
     torch.Tensor.get_device, torch.Tensor.requires_grad.__get__, torch.Tensor.requires_grad.__set__, torch.Tensor.requires_grad_,
     torch.Tensor.is_leaf.__get__, torch.Tensor.grad_fn.__get__, torch.Tensor.grad.__get__, torch.Tensor.grad.__set__,
     torch.Tensor.grad.__delete__, torch.Tensor.is_contiguous, torch.Tensor.stride, torch.Tensor.storage_offset,
-    torch.Tensor.is_sparse.__get__, torch.Tensor.element_size, torch.Tensor.register_hook,
+    torch.Tensor.is_sparse.__get__, torch.Tensor.element_size, torch.Tensor.register_hook, torch.Tensor._version.__get__,
+    torch.Tensor.output_nr.__get__, torch.Tensor.names.__get__, torch.Tensor.is_meta.__get__, torch.Tensor.is_quantized.__get__,
+    torch.Tensor.__hash__,
 }
 
 
@@ -165,6 +167,7 @@ class _LazyLinear:
             self.w_raw, self.b_raw = weight.data, bias.data           # plain aliases: no flush hook, same storage
         self.ws = None
         self.ws_bytes = 0
+        self._ws_need = {}
         self.bucket = torch.zeros(weight.numel() + 2, dtype=torch.float32, device=weight.device)
         self.bucket_gen = -1        # whose gradient the bucket holds
         self.gen = 0                # bumped by every lazy forward: the rows in `ws` belong to generation `gen`
@@ -192,7 +195,9 @@ class _LazyLinear:
 
     # ---- the launches ----
     def _ensure_ws(self, B, L, F):
-        need = max(int(_C.lib().ltr_linear_workspace_bytes(B, L, F)), 4)
+        need = self._ws_need.get((B, L, F))
+        if need is None:
+            need = self._ws_need[(B, L, F)] = max(int(_C.lib().ltr_linear_workspace_bytes(B, L, F)), 4)
         if need > self.ws_bytes:
             self.settle()                                   # nothing may still live in the old buffer
             self.ws = torch.empty(need // 4 + 16, dtype=torch.float32, device=self.w_raw.device)
@@ -357,29 +362,71 @@ class SGD(torch.optim.SGD):
         for st in self._lazy:
             st.flush()
 
-    @torch.no_grad()
-    def step(self, closure=None):
+    def _step_impl(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         taken = []
-        for st in self._lazy:
-            if st.take():
-                with torch._C.DisableTorchFunctionSubclass():
+        with torch._C.DisableTorchFunctionSubclass():
+            for st in self._lazy:
+                if st.take():
                     taken.append((st.weight, st.weight.grad))
                     taken.append((st.bias, st.bias.grad))
                     st.weight.grad = None
                     st.bias.grad = None
-        with torch._C.DisableTorchFunctionSubclass():
             rest = any(p.grad is not None for g in self.param_groups for p in g["params"])
         if rest:
-            super().step()                     # whatever was not taken lazily: torch's own SGD
+            _torch_sgd_step()(self)            # whatever was not taken lazily: torch's own SGD (hooks and all)
+        elif self._has_step_hooks():
+            SGD._hooks_only(self)              # (registered step hooks run although there was nothing left to do)
         with torch._C.DisableTorchFunctionSubclass():
             for p, g in taken:
                 p.grad = g                     # `.grad` stays readable after the step, as with torch.optim.SGD
         return loss
 
+    def _has_step_hooks(self):
+        from torch.optim import optimizer as _o
+        return bool(self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks
+                    or _o._global_optimizer_pre_hooks or _o._global_optimizer_post_hooks)
+
+    def step(self, closure=None):
+        """``torch.optim.SGD.step``.  (The host side of a step that has nothing left to launch is kept short: torch's wrapper
+        around every optimizer's ``step`` -- profiler ranges, hook dispatch -- only runs when there is work for torch's own
+        SGD or a step hook is registered.)"""
+        return self._step_impl(closure)
+    step.hooked = True                         # (Optimizer.__init__ must not wrap it: _step_impl goes through torch's wrapper itself)
+
+    def zero_grad(self, set_to_none=True):
+        if not set_to_none:
+            return super().zero_grad(set_to_none=False)
+        with torch._C.DisableTorchFunctionSubclass():
+            for g in self.param_groups:
+                for p in g["params"]:
+                    p.grad = None
+
     def state_dict(self):
         self.flush()
         return super().state_dict()
+
+
+def _noop_step(self, closure=None):
+    return None
+
+
+_torch_step_cache = []
+
+
+def _torch_sgd_step():
+    """torch.optim.SGD.step inside torch's own wrapper (profiler range, step hooks) -- whether or not a plain torch.optim.SGD
+    has been constructed in this process yet (the wrapper is patched onto a class by its first instance)."""
+    if not _torch_step_cache:
+        base = torch.optim.SGD.step
+        if getattr(base, "hooked", False):
+            base = getattr(base, "__wrapped__", base)
+        _torch_step_cache.append(torch.optim.Optimizer.profile_hook_step(base))
+    return _torch_step_cache[0]
+
+
+# torch's wrapper (profiler range + pre / post hooks) around a step that does nothing: for registered hooks on fully lazy steps
+SGD._hooks_only = staticmethod(torch.optim.Optimizer.profile_hook_step(_noop_step))

@@ -85,7 +85,25 @@ def test_lazy_path_is_the_c_abi_lazy_step_bit_for_bit():
     W = model.weight.detach().clone().reshape(F)
     b = model.bias.detach().clone()
     opt = SGD(model.parameters(), lr=0.02)
-    _loop(model, opt, L_.PairwiseHingeLoss(), data)
+    # ONE launch per step: nothing in the loop body may read the parameters' values (that would apply the pending update in a
+    # launch of its own) or the gradients' (a reduction launch) -- count both
+    from pytorchltr_amd import optim as O_
+    counts = {"flush": 0, "grad": 0}
+    real_flush, real_grad = O_._LazyLinear.flush, O_._LazyLinear.gradient_of
+
+    def flush(self):
+        counts["flush"] += 1 if self.pending is not None else 0
+        return real_flush(self)
+
+    def gradient_of(self, pg):
+        counts["grad"] += 1
+        return real_grad(self, pg)
+    O_._LazyLinear.flush, O_._LazyLinear.gradient_of = flush, gradient_of
+    try:
+        _loop(model, opt, L_.PairwiseHingeLoss(), data)
+    finally:
+        O_._LazyLinear.flush, O_._LazyLinear.gradient_of = real_flush, real_grad
+    assert counts == {"flush": 0, "grad": 0}, counts
     ref = LazySGD(W, b, 0.02, loss="hinge")
     for xs, ys, n in data:
         ref.step(xs, ys, n)
