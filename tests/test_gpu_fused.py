@@ -273,6 +273,56 @@ def test_loss_sum_and_single_entry_point():
                                        ws.data_ptr(), 16, _C.stream_of(X)) == -5      # workspace too small
 
 
+@pytest.mark.parametrize("B,F", [(4096, 136), (5003, 136), (70001, 46), (4100, 7), (9000, 1020), (4500, 1024)])
+def test_reduction_of_many_rows(B, F):
+    """Batches beyond 4096 queries: the reduction of the partial rows is two launches whose work scales with B (chunks of whole
+    rows per workgroup, then one combine per column group -- csrc/ltr_linear.inc: launch_linear_reduce) instead of one workgroup
+    per column walking all of them.  Same contract as the small-batch kernel: dW / db / loss sum, weighted rows, accumulate,
+    deterministic.  (F = 1024: rows too wide for the split kernel's mapping -- the one-level kernel, at any B.)"""
+    from pytorchltr_amd import _C
+    dev = _dev()
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(B + F)
+    PF = (F + 4) & ~3
+    ws_bytes = lib.ltr_linear_workspace_bytes(B, 8, F)
+    assert ws_bytes >= B * PF * 4
+    ws = torch.full((ws_bytes // 4,), float("nan"), device=dev)          # (the scratch behind the rows starts as garbage)
+    rows = torch.randn(B, PF, generator=g)
+    rows[:, F + 1:] = 0.0
+    ws[:B * PF] = rows.reshape(-1).to(dev)
+    go = torch.rand(B, generator=g)
+    loss = torch.rand(B, generator=g)
+    go_d, loss_d = go.to(dev), loss.to(dev)
+    ref = (rows.double() * go.double()[:, None]).sum(0)
+    scale = float(np.sqrt(B))
+    outs = []
+    for rep in range(2):
+        dW, db, ls = torch.zeros(F, device=dev), torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+        _C.check(lib.ltr_linear_reduce_loss_f32(ws.data_ptr(), go_d.data_ptr(), loss_d.data_ptr(), B, F, dW.data_ptr(), db.data_ptr(),
+                                                ls.data_ptr(), _C.stream_of(ws)))
+        outs.append((dW.cpu(), db.cpu(), ls.cpu()))
+    dW, db, ls = outs[0]
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))       # fixed order: bit-identical run to run
+    assert np.max(np.abs(dW.double().numpy() - ref[:F].numpy())) < 2e-6 * scale * 4
+    assert abs(float(db[0]) - float(ref[F])) < 2e-6 * scale * 4
+    assert float(ls[0]) == pytest.approx(float(loss.double().sum()), rel=1e-5)
+    # uniform weight 1/B (grad_out NULL), accumulated on top of what is there
+    dW2, db2, ls2 = dW.to(dev).clone(), db.to(dev).clone(), ls.to(dev).clone()
+    _C.check(lib.ltr_linear_reduce_accum_f32(ws.data_ptr(), None, loss_d.data_ptr(), B, F, dW2.data_ptr(), db2.data_ptr(), ls2.data_ptr(),
+                                             1, _C.stream_of(ws)))
+    ref2 = ref + rows.double().mean(0)
+    assert np.max(np.abs(dW2.cpu().double().numpy() - ref2[:F].numpy())) < 2e-6 * scale * 4
+    assert abs(float(db2.cpu()[0]) - float(ref2[F])) < 2e-6 * scale * 4
+    assert float(ls2.cpu()[0]) == pytest.approx(2 * float(loss.double().sum()), rel=1e-5)
+    # the upstream gradient as one device scalar (stride 0)
+    sc = torch.full((1,), 0.25, device=dev)
+    dW3, db3 = torch.empty(F, device=dev), torch.empty(1, device=dev)
+    _C.check(lib.ltr_linear_reduce_bcast_f32(ws.data_ptr(), sc.data_ptr(), B, F, dW3.data_ptr(), db3.data_ptr(), _C.stream_of(ws)))
+    ref3 = rows.double().sum(0) * 0.25
+    assert np.max(np.abs(dW3.cpu().double().numpy() - ref3[:F].numpy())) < 2e-6 * scale * 4
+    assert abs(float(db3.cpu()[0]) - float(ref3[F])) < 2e-6 * scale * 4
+
+
 def test_fused_module_matches_unfused_dropin():
     """FusedLinearLoss == loss_fn(nn.Linear(F,1)(xs), ys, n) for arbitrary upstream weights."""
     from pytorchltr_amd.fused import FusedLinearLoss
