@@ -335,7 +335,10 @@ int ltr_linear_pairwise_f32(int kind, float sigma, const float *X, const float *
  * after -- so that a query's row is one contiguous, 16-byte aligned store; then
  * dW_f = sum_b grad_out[b] * partials[b, f], db likewise (grad_out NULL = 1/B).
  * The `partials` buffer must be ltr_linear_workspace_bytes(B,L,F) bytes (the B * PF matrix,
- * rounded up, plus a reserved tail and, for some shapes, kernel scratch). */
+ * rounded up, plus a reserved tail and, for some shapes, kernel scratch -- and from 4096 queries on the
+ * scratch rows of the reduction, which is two launches whose work scales with B there: the reduce entry
+ * points below WRITE behind the rows of such a batch, any L gives enough room).  Sums in a fixed order:
+ * bit-identical run to run at every B. */
 int ltr_linear_partials_f32(int kind, float sigma, const float *X, const float *W,
                             const float *bias, const void *rel, int rel_dtype,
                             const int64_t *n, int B, int L, int F, float *loss,
