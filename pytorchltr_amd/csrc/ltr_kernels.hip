@@ -73,9 +73,28 @@ namespace {
 
 // NW > 0 (symmetric pass only): the workgroup has NW waves, known at compile time (4 / 8 / 16 by
 // list length) -- the pair pass then needs no dispatch-packet read, no divisions and one barrier less.
+template <int KIND, int DPT, int NW>
+__device__ __forceinline__ void pairwise_loss_body(const LossParams &p);
+
 template <int KIND, int DPT, int NW = 0>
 __global__ void __launch_bounds__(NW > 0 ? NW * 64 : 1024)
 pairwise_loss_kernel(LossParams p)
+{
+    pairwise_loss_body<KIND, DPT, NW>(p);
+}
+
+// The LambdaNDCG kinds' symmetric pass, left to itself, takes 93-96 SGPRs at 34-42 VGPRs: SEVEN waves per SIMD (the SGPR cliff,
+// DESIGN 4.6 -- more than 80 SGPRs + the trap handler's 16 do not fit eight times into a SIMD's 800).  Capped (the attribute wants
+// a literal: an entry point of its own around the same body).
+template <int KIND, int NW>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_num_sgpr(80)))
+pairwise_loss_kernel80(LossParams p)
+{
+    pairwise_loss_body<KIND, 0, NW>(p);
+}
+
+template <int KIND, int DPT, int NW>
+__device__ __forceinline__ void pairwise_loss_body(const LossParams &p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int L = p.L;
@@ -469,8 +488,11 @@ __device__ void block_inclusive_scan(float *buf, int L, float *scan_scratch)
 
 enum { METRIC_RANK = 0, METRIC_DCG = 1, METRIC_ARP = 2 };
 
+// (the sort path, DPT <= 0, under 64 VGPRs -- eight waves per SIMD: its workgroups have up to 1024 threads, and at the 68-69 VGPRs
+// the compiler takes when left alone ONE of those fits a CU instead of two.  ndcg@10, 16 384 x 1000: 1167 -> 746 us, arp 631 -> 399,
+// 65 536 x 512: 1260 -> 1103, 8192 x 2000: 1096 -> 746; lists of 128: unchanged.  Round 6.)
 template <int OP, int DPT>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(1024, (DPT <= 0 ? 8 : 4))
 metric_kernel(MetricParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -880,8 +902,13 @@ int launch_loss_kind(const LossParams &p, const LaunchShape &s, hipStream_t stre
     } while (0)
 #define LTR_LAUNCH_SYM(NWAVES)                                                                   \
     do {                                                                                        \
-        LTR_ENSURE_LDS((pairwise_loss_kernel<KIND, 0, NWAVES>), lds);                           \
-        hipLaunchKernelGGL((pairwise_loss_kernel<KIND, 0, NWAVES>), grid, block, lds, stream, p); \
+        if constexpr (KIND == LTR_NDCG1 || KIND == LTR_NDCG2) {                                 \
+            LTR_ENSURE_LDS((pairwise_loss_kernel80<KIND, NWAVES>), lds);                        \
+            hipLaunchKernelGGL((pairwise_loss_kernel80<KIND, NWAVES>), grid, block, lds, stream, p); \
+        } else {                                                                                \
+            LTR_ENSURE_LDS((pairwise_loss_kernel<KIND, 0, NWAVES>), lds);                       \
+            hipLaunchKernelGGL((pairwise_loss_kernel<KIND, 0, NWAVES>), grid, block, lds, stream, p); \
+        }                                                                                       \
     } while (0)
     switch (s.dpt) {
     case 0:
