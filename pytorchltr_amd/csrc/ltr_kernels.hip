@@ -71,7 +71,7 @@ extern "C" __attribute__((visibility("hidden"))) int ltr_internal_status_peek(vo
 
 namespace {
 
-// NW > 0 (symmetric pass only): the workgroup has NW waves, known at compile time (4 / 8 / 16 by
+// NW > 0 (symmetric pass only): the workgroup has NW waves, known at compile time (1 / 2 / 4 / 8 / 16 by batch size and
 // list length) -- the pair pass then needs no dispatch-packet read, no divisions and one barrier less.
 template <int KIND, int DPT, int NW>
 __device__ __forceinline__ void pairwise_loss_body(const LossParams &p);
@@ -871,22 +871,48 @@ LaunchShape choose_shape(int B, int L)
     return s;
 }
 
-// Loss kernels: lists up to kSymMaxLen take the symmetric pair pass (dpt == 0; measured on MI355X:
-// C2 hinge 7.7 -> 6.5 us, NDCG2 20.3 -> 16.4 us, C5 35 -> 26 us, C4 62 -> 56 us);
-// 4 waves per query for L <= 128, 8 up to 256, 16 above.
-LaunchShape choose_loss_shape(int B, int L)
+// Loss kernels: lists up to kLossSymMaxLen take the symmetric pair pass (dpt == 0; measured on MI355X:
+// C2 hinge 7.7 -> 6.5 us, NDCG2 20.3 -> 16.4 us, C5 35 -> 26 us, C4 62 -> 56 us).
+// Waves per query: while the batch leaves CUs short of work a query is spread wide -- 4 waves for L <= 128, 8 up to 256, 16 above
+// (the latency of ONE query is the launch's).  Once every CU has several rounds of queries the launch is bound by how many
+// queries a CU has IN FLIGHT (a query is a chain of one HBM round trip, a staging barrier, the pair pass and a reduction; eight
+// waves per SIMD whatever their grouping), and narrow workgroups win: round 6, ragged lists, us, default -> best,
+//   hinge      128: 65 536 queries 130 -> 100 (1 wave), 262 144: 482 -> 336;   64: 262 144: 343 -> 153;   256: 65 536: 354 -> 280 (4)
+//              512: 65 536: 1226 -> 904 (4 waves; 8: 959), 1000: 65 536: 3620 -> 3198 (4), 16 384: 959 -> 884
+//   LambdaNDCG2 128: 65 536: 318 -> 273 (1), 256: 65 536: 976 -> 774 (4), 512: 1024 queries 80 -> 70 (8), 65 536: 3947 -> 2751 (8),
+//              1000: 4096: 940 -> 716 (8), 65 536: 15 655 -> 11 621 (8)
+//   logistic / LambdaARP 128: 262 144: 895 -> 827 / 868 -> 811 (1); 256: 4096: 56.9 -> 54.7 (4); 512: 16 384: 708 -> 652 (8)
+// (scripts/dev/loss_waves.py; a pair evaluation costs the LambdaNDCG kinds several times what it costs the hinge kinds, which
+// is why they want their ~8 k pairs per wave where the hinge kinds take 32 k.)
+LaunchShape choose_loss_shape(int kind, int B, int L)
 {
 #ifndef LTR_NO_SYM
     if (L <= kLossSymMaxLen) {
         LaunchShape s;
         s.dpt = 0;
         s.owners = 64;
-        // waves per query (beyond 1024 documents: eight -- sixteen gradient slices of 2048 floats do not fit the LDS)
-        s.msplit = (L <= 128) ? 4 : (L <= 256 ? 8 : (L <= kSymMaxLen ? 16 : 8));
-        (void)B;
+        // (beyond 1024 documents: eight -- sixteen gradient slices of 2048 floats do not fit the LDS)
+        int waves = (L <= 128) ? 4 : (L <= 256 ? 8 : (L <= kSymMaxLen ? 16 : 8));
+        const long cus = device_cu_count();
+        const bool cheap = kind == LTR_HINGE || kind == LTR_DCG_HINGE;
+        const bool ndcg = kind == LTR_NDCG1 || kind == LTR_NDCG2;
+        if (L <= 64) {
+            if (B >= 16 * cus) waves = 1;
+        } else if (L <= 128) {
+            if (cheap) waves = B >= 128 * cus ? 1 : (B >= 16 * cus ? 2 : 4);
+            else if (ndcg) { if (B >= 64 * cus) waves = 2; }              // (65 536: 2 waves 272, 1 wave 291, 4 waves 292)
+            else if (B >= 256 * cus) waves = 1;
+        } else if (L <= 256) {
+            if (B >= 16 * cus) waves = 4;
+        } else if (L <= kSymMaxLen) {
+            if (ndcg) { if (B >= 4 * cus) waves = 8; }
+            else if (B >= 16 * cus) waves = (cheap && B >= 64 * cus) ? 4 : 8;
+        }
+        s.msplit = waves;
         return s;
     }
 #endif
+    (void)kind;
     return choose_shape(B, L);
 }
 
@@ -914,7 +940,9 @@ int launch_loss_kind(const LossParams &p, const LaunchShape &s, hipStream_t stre
     case 0:
         // the shapes choose_loss_shape picks get a compile-time wave count; explicit (_cfg) shapes
         // with another block size run the run-time variant
-        if (s.owners * s.msplit == 256) LTR_LAUNCH_SYM(4);
+        if (s.owners * s.msplit == 64) LTR_LAUNCH_SYM(1);
+        else if (s.owners * s.msplit == 128) LTR_LAUNCH_SYM(2);
+        else if (s.owners * s.msplit == 256) LTR_LAUNCH_SYM(4);
         else if (s.owners * s.msplit == 512) LTR_LAUNCH_SYM(8);
         else if (s.owners * s.msplit == 1024) LTR_LAUNCH_SYM(16);
         else LTR_LAUNCH(0);
@@ -1027,6 +1055,10 @@ int launch_metric(const MetricParams &p0, hipStream_t stream)
     }
 #endif
     LaunchShape s = choose_shape(p.B, p.L);
+    // (many rounds of queries per CU: ONE wave per query, two documents per thread -- what bounds the launch then is the number of
+    // queries a CU has in flight, see choose_loss_shape.  Lists of 128, round 6: ndcg@10 65 536 queries 116 -> 99 us, 2^20: 1667 ->
+    // 1359, arp 2^20: 1216 -> 804; at 1024 queries the two-wave shape stays, 6.6 against 8.0)
+    if (p.L > 64 && p.L <= 128 && (long)p.B >= 64L * device_cu_count()) { s.owners = 64; s.dpt = 2; s.msplit = 1; }
     p.msplit = s.msplit;
     const dim3 grid((unsigned)p.B), block((unsigned)(s.owners * s.msplit));
     const size_t lds = metric_lds_bytes(p.L);
@@ -1118,7 +1150,7 @@ int ltr_pairwise_loss_f32(int kind, float sigma, const float *scores, const void
 {
     LTR_CLEAR_STALE_ERROR();
     if (B < 0 || L <= 0) return LTR_ERR_SHAPE;
-    LaunchShape s = choose_loss_shape(B, L);
+    LaunchShape s = choose_loss_shape(kind, B, L);
     if (s.dpt == 0 && loss_lds_bytes_cfg(kind, L, s) > kLdsBudget) s = choose_shape(B, L);
     while (s.dpt != 0 && s.msplit > 1 && loss_lds_bytes(kind, L, s.msplit) > kLdsBudget) s.msplit /= 2;
     return ltr_pairwise_loss_f32_cfg(kind, sigma, scores, rel, rel_dtype, n, B, L, loss, dscores,

@@ -498,3 +498,45 @@ def test_list_length_scheduling_in_the_loss_kernel(shape, lists):
         want_l, want_g = O.pairwise_loss(kind, s.numpy(), y.numpy(), n.numpy(), sigma=1.0)
         _check_loss(loss.cpu().numpy(), want_l, L, "%s %s %s" % (shape, lists, kind))
         _check_grad(ds.cpu().numpy(), want_g, "%s %s %s" % (shape, lists, kind), exact=(kind == "hinge"))
+
+
+@pytest.mark.parametrize("shape", [(4096, 128), (16384, 100), (33000, 128), (66000, 90), (4100, 64), (4096, 256), (4100, 300), (16400, 258), (1024, 520)])
+def test_many_queries_take_narrow_workgroups(shape):
+    """Round 6: once every CU has several rounds of queries the loss-only kernels give a query fewer waves (choose_loss_shape:
+    1 / 2 waves on lists up to 128, 4 on 256, 8 / 4 on longer ones) and the metric kernels one wave (lists of 65 .. 128) --
+    what bounds those launches is the number of queries a CU has in flight.  Every shape the rule can pick, against the oracle,
+    every row written (NaN prefill), run to run identical."""
+    from pytorchltr_amd import _C
+    B, L = shape
+    dev = _dev()
+    s, y, n = synth(B, L, 77 + L)[:3]
+    sd, yd, nd = s.to(dev), y.to(dev), n.to(dev)
+    lib = _C.lib()
+    for kind in ("hinge", "dcg_hinge", "logistic", "arp2", "ndcg1", "ndcg2"):
+        outs = []
+        for rep in range(2):
+            loss = torch.full((B,), float("nan"), device=dev)
+            ds = torch.full((B, L), float("nan"), device=dev)
+            _C.check(lib.ltr_pairwise_loss_f32(_C.__dict__[kind.upper()], 1.0, sd.data_ptr(), yd.data_ptr(), _C.label_dtype(yd), nd.data_ptr(),
+                                               B, L, loss.data_ptr(), ds.data_ptr(), _C.stream_of(sd)))
+            torch.cuda.synchronize()
+            outs.append((loss.cpu(), ds.cpu()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), kind
+        loss, ds = outs[0]
+        assert not torch.isnan(loss).any() and not torch.isnan(ds).any(), kind
+        want_l, want_g = O.pairwise_loss(kind, s.numpy(), y.numpy(), n.numpy(), sigma=1.0)
+        _check_loss(loss.numpy(), want_l, L, "%s %s" % (shape, kind))
+        if kind in ("hinge", "dcg_hinge"):
+            # a pair whose score difference sits within an fp32 ulp of the margin (tens of millions of pairs here: expect about one
+            # per kind) may fall on the other side in the fp64 oracle: its two gradient entries then differ by the pair's weight (<= 1)
+            diff = np.abs(ds.numpy().astype(np.float64) - want_g)
+            bad = diff > 1e-5 * np.max(np.abs(want_g), axis=1, keepdims=True) + 1e-6
+            assert np.count_nonzero(bad) <= 8 and np.max(diff) <= 2.0, (kind, np.count_nonzero(bad), np.max(diff))
+        else:
+            _check_grad(ds.numpy(), want_g, "%s %s" % (shape, kind))
+    if L <= 128:
+        import pytorchltr_amd.evaluation as ev
+        from pytorchltr_amd.utils import rank_by_score
+        assert np.allclose(ev.ndcg(sd, yd, nd, k=10).cpu().numpy(), O.ndcg(s.numpy(), y.numpy(), n.numpy(), k=10), rtol=2e-6, atol=1e-6)
+        assert np.allclose(ev.arp(sd, yd, nd).cpu().numpy(), O.arp(s.numpy(), y.numpy(), n.numpy()), rtol=2e-6, atol=1e-6)
+        assert np.array_equal(rank_by_score(sd, nd).cpu().numpy(), O.rank_by_score(s.numpy(), n.numpy()))
