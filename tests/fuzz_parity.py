@@ -57,6 +57,13 @@ while time.time() < t_end:
             okl = np.all(np.abs(got_l - want_l) <= 1e-5 + (3e-3 if ndcgk else tol_loss(L)) * np.abs(want_l))
             tol = (2e-3 if ndcgk else 2e-4) * max(1.0, float(np.max(np.abs(want_dW))))
             okw = np.max(np.abs(dW.cpu().numpy() - want_dW)) < tol and abs(float(db.cpu()[0]) - want_db) < tol
+            if ndcgk and okw and not okl:
+                # a rank-dependent loss on fp32 scores: two documents whose fp64 scores differ by less than an fp32 ulp may swap
+                # ranks -- judge the losses on the scores the GPU computed
+                sc = linear_loss_step(X.to(dev), W.to(dev), b.to(dev), y.to(dev), n.to(dev), loss=lm, return_scores=True)[-1]
+                want_l2 = O.pairwise_loss(kind, sc.cpu().numpy().reshape(B, L), y.numpy(), n.numpy(), sigma=sigma)[0]
+                okl = np.all(np.abs(got_l - want_l2) <= 1e-5 + 3e-3 * np.abs(want_l2))
+                if okl: print("note fused", kind, B, L, F, "rank flips against the fp64 scores; equal on the GPU's scores", flush=True)
             if not (okl and okw and np.all(np.isfinite(got_l))):
                 fails += 1; print("FAIL fused", kind, B, L, F, "pat", pat, "sigma", sigma, "loss ok", okl, "dW ok", okw, "plan", _C.lib().ltr_linear_fused_plan(getattr(_C, kind.upper()), B, L, F), flush=True)
     except Exception as exc:
