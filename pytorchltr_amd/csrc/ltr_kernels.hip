@@ -1037,14 +1037,19 @@ int launch_metric(const MetricParams &p0, hipStream_t stream)
 #ifndef LTR_NO_SORT_RANK
     if (p.L > kSortRankMinLen) {
         const int P = sort_pow2(p.L);
-        const int T = P < 1024 ? P : 1024;              // E = P / T <= 4 registers per thread
+        int T = P < 1024 ? P : 1024;                    // E = P / T <= 4 keys per thread
+        // (many rounds of queries per CU: half the threads with two keys each -- narrower workgroups, more queries in flight, see
+        // choose_loss_shape.  Round 6, us: ndcg@10 65 536 x 512 1105 -> 854, 65 536 x 300 953 -> 737, 16 384 x 1000 749 -> 552,
+        // arp 65 536 x 300 530 -> 384; 1024 x 512: 25.9 / 25.5, 256 x 1000: 21.7 -> 26.7 -- hence from 16 queries per CU on.  Four
+        // keys per thread: 65 536 x 512 889, 8192 x 2000 747 -> 804 -- not taken.)
+        if (P <= 1024 && P >= 128 && (long)p.B >= 16L * device_cu_count()) T = P / 2;
         p.msplit = 1;
         const size_t lds = metric_lds_bytes_sort(p.L);
         const dim3 sgrid((unsigned)p.B), sblock((unsigned)T);
-        if (P <= 1024) {
+        if (P == T) {
             LTR_ENSURE_LDS((metric_kernel<OP, 0>), lds);
             hipLaunchKernelGGL((metric_kernel<OP, 0>), sgrid, sblock, lds, stream, p);
-        } else if (P == 2048) {
+        } else if (P == 2 * T) {
             LTR_ENSURE_LDS((metric_kernel<OP, -2>), lds);
             hipLaunchKernelGGL((metric_kernel<OP, -2>), sgrid, sblock, lds, stream, p);
         } else {

@@ -534,9 +534,12 @@ def test_many_queries_take_narrow_workgroups(shape):
             assert np.count_nonzero(bad) <= 8 and np.max(diff) <= 2.0, (kind, np.count_nonzero(bad), np.max(diff))
         else:
             _check_grad(ds.numpy(), want_g, "%s %s" % (shape, kind))
-    if L <= 128:
-        import pytorchltr_amd.evaluation as ev
-        from pytorchltr_amd.utils import rank_by_score
-        assert np.allclose(ev.ndcg(sd, yd, nd, k=10).cpu().numpy(), O.ndcg(s.numpy(), y.numpy(), n.numpy(), k=10), rtol=2e-6, atol=1e-6)
-        assert np.allclose(ev.arp(sd, yd, nd).cpu().numpy(), O.arp(s.numpy(), y.numpy(), n.numpy()), rtol=2e-6, atol=1e-6)
-        assert np.array_equal(rank_by_score(sd, nd).cpu().numpy(), O.rank_by_score(s.numpy(), n.numpy()))
+    # the metric kernels: one wave per query on lists of 65 .. 128, two keys per thread on the sort path (lists beyond 256)
+    import pytorchltr_amd.evaluation as ev
+    from pytorchltr_amd.utils import rank_by_score
+    rtol = 2e-5 if L > 256 else 2e-6
+    for k in (10, None):
+        assert np.allclose(ev.ndcg(sd, yd, nd, k=k).cpu().numpy(), O.ndcg(s.numpy(), y.numpy(), n.numpy(), k=k), rtol=rtol, atol=1e-6), k
+    assert np.allclose(ev.dcg(sd, yd, nd, k=5, exp=False).cpu().numpy(), O.dcg(s.numpy(), y.numpy(), n.numpy(), k=5, exp=False), rtol=rtol, atol=1e-6)
+    assert np.allclose(ev.arp(sd, yd, nd).cpu().numpy(), O.arp(s.numpy(), y.numpy(), n.numpy()), rtol=rtol, atol=1e-6)
+    assert np.array_equal(rank_by_score(sd, nd).cpu().numpy(), O.rank_by_score(s.numpy(), n.numpy()))
